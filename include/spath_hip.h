@@ -1,0 +1,112 @@
+/* spath_hip.h -- C ABI of the MI355X (gfx950) path-tracing backend for Emanem/spath.
+ *
+ * This is the drop-in boundary: plain C types, caller-allocated outputs, no exceptions, no C++
+ * or torch types.  It is what a `hip_renderer` peer of the reference's cpu_renderer binds to
+ * (see spath_amd/host/hip_renderer.cpp and INTEGRATION.md).  Each entry point names the reference
+ * interface it stands behind (paths relative to the reference repository root).
+ *
+ * Data layouts are the reference's tightly packed float structs:
+ *   ray       6 x f32  pos.xyz dir.xyz                  geom::ray        src/geom.h:179-182
+ *   triangle 12 x f32  v0 v1 v2 n                       geom::triangle   src/geom.h:185-190
+ *   material  6 x f32  reflectance.rgb emittance.rgb    scene::material  src/scene.h:47-50
+ *   pixel     4 x u8   r g b a(=0)                      scene::RGBA      src/scene.h:25-30
+ * Pixel index = i + j*W, row 0 = top (src/view.h:112).
+ *
+ * Every function returning int returns 0 on success and a negative SPHIP_E_* code otherwise;
+ * sphip_last_error() then describes the failure.  The C++ adapter turns a non-zero status into
+ * std::runtime_error, which is how the reference's GPU peers report failure
+ * (src/cl_renderer.cpp:155-187, src/vk_renderer.cpp:318-349).
+ */
+#ifndef SPATH_HIP_H
+#define SPATH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHIP_ABI_VERSION 1
+
+typedef struct sphip_ctx sphip_t;
+
+enum {
+	SPHIP_OK = 0,
+	SPHIP_E_INVALID = -1,   /* bad argument (NULL pointer, n_samples == 0, ...) */
+	SPHIP_E_DEVICE = -2,    /* HIP runtime error (no device, allocation failure, launch failure) */
+	SPHIP_E_STATE = -3      /* call order error (render before set_scene) */
+};
+
+/* render modes: which renderer virtual is being served */
+enum {
+	SPHIP_MODE_FLAT = 0,    /* renderer::render_flat  src/renderer.h:31, body src/cpu_renderer.cpp:81-101 */
+	SPHIP_MODE_PT = 1       /* renderer::render       src/renderer.h:32, body src/cpu_renderer.cpp:29-79,118-184 */
+};
+
+/* flags (bitwise or) */
+enum {
+	SPHIP_KERNEL_AUTO = 0,          /* let the library pick the scan kernel */
+	SPHIP_KERNEL_MASK = 0xff,       /* low byte: explicit kernel variant (see sphip_kernel_name) for A/B runs;
+	                                   every variant produces bit-identical images */
+	SPHIP_FLAG_PRIMARY_REUSE = 0x100 /* scan the (identical) primary ray of a pixel once for all its samples
+	                                   (src/cpu_renderer.cpp:74-76 re-scans it); identical image, fewer scans */
+};
+
+/* Pixel-shard descriptor: which global pixel the k-th ray of a shard is.
+ *   global_pixel(k) = pixel_base + (k / tile_px) * tile_stride_px + (k % tile_px)
+ * A whole image is {0, npix, 0}.  Row tiles dealt round-robin to G GPUs (rank r, tile of R rows of
+ * width W): {r*R*W, R*W, G*R*W}.  The global index keys the counter RNG, so an image does not
+ * depend on how it was sharded. */
+typedef struct {
+	uint64_t pixel_base;
+	uint64_t tile_px;
+	uint64_t tile_stride_px;
+} sphip_shard;
+
+typedef struct {
+	double   kernel_ms;        /* device time of the last render's kernels (hipEvent, on the launch stream) */
+	double   upload_ms;        /* host-pointer path only: H2D of rays (+ scene when it changed) */
+	double   download_ms;      /* host-pointer path only: D2H of the image */
+	uint64_t scans_executed;   /* closest-hit scans (one ray against all triangles) the last render ran */
+	uint64_t n_tris;
+	uint64_t n_pixels;
+	uint32_t kernel_variant;   /* variant that actually ran */
+	uint32_t n_launches;
+} sphip_stats;
+
+/* ---- lifetime.  Replaces X_renderer::get(w,h) construction (src/cpu_renderer.cpp:205-209) for the
+ * device-owning part; device buffers are cached grow-only in the context like
+ * src/cl_renderer.cpp:107-112 and released by sphip_destroy. */
+int  sphip_create(int device_id, sphip_t** out);
+void sphip_destroy(sphip_t* ctx);
+const char* sphip_last_error(const sphip_t* ctx);   /* ctx may be NULL: error of a failed sphip_create */
+const char* sphip_description(const sphip_t* ctx);  /* renderer::get_description  src/renderer.h:26 */
+int  sphip_abi_version(void);
+const char* sphip_kernel_name(int variant);         /* NULL when the variant does not exist */
+
+/* ---- host-pointer path: exactly what renderer::render / render_flat receive
+ * (src/renderer.h:31-32): borrowed host arrays, valid only during the call; blocking. */
+int sphip_set_scene(sphip_t* ctx, const float* tris, const float* mats, size_t n_tris);
+int sphip_render(sphip_t* ctx, const float* rays, size_t w, size_t h, size_t n_samples,
+                 uint64_t seed, int mode, int flags,
+                 uint8_t* out_rgba /* w*h*4 */, float* out_accum /* w*h*3 or NULL */);
+
+/* ---- device-resident path: pointers are HIP device pointers on ctx's device, `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing; outputs are complete
+ * when the stream reaches the end of the enqueued work.  Used for HBM-resident benchmarking and for
+ * pixel-row-tile sharding across GPUs (one context per GPU). */
+int sphip_set_scene_device(sphip_t* ctx, const void* d_tris, const void* d_mats, size_t n_tris, void* stream);
+int sphip_render_device(sphip_t* ctx, const void* d_rays /* n_rays*6 f32: the shard's rays */, size_t n_rays,
+                        const sphip_shard* shard /* NULL = {0, n_rays, 0} */, size_t image_width,
+                        size_t n_samples, uint64_t seed, int mode, int flags,
+                        void* d_out_rgba /* n_rays*4 u8 */, void* d_out_accum /* n_rays*3 f32 or NULL */,
+                        void* stream);
+
+/* Blocks until the last render on this context has finished, then reports its figures. */
+int sphip_get_stats(sphip_t* ctx, sphip_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPATH_HIP_H */

@@ -1,0 +1,161 @@
+"""ctypes binding of the C ABI in include/spath_hip.h (libspath_hip.so).
+
+This is the only way Python reaches the HIP kernels.  There is no CPU fallback: if the shared
+library is missing or the GPU cannot be initialised the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libspath_hip.so")
+
+MODE_FLAT = 0
+MODE_PT = 1
+KERNEL_AUTO = 0
+FLAG_PRIMARY_REUSE = 0x100
+
+# every entry point include/spath_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = (
+    "sphip_create", "sphip_destroy", "sphip_last_error", "sphip_description", "sphip_abi_version",
+    "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
+    "sphip_render_device", "sphip_get_stats",
+)
+
+
+class Shard(C.Structure):
+    _fields_ = [("pixel_base", C.c_uint64), ("tile_px", C.c_uint64), ("tile_stride_px", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double),
+                ("scans_executed", C.c_uint64), ("n_tris", C.c_uint64), ("n_pixels", C.c_uint64),
+                ("kernel_variant", C.c_uint32), ("n_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SpathHipError(RuntimeError):
+    """A non-zero status from the C ABI (the C++ adapter throws std::runtime_error at the same point)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libspath_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpathHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                            "there is no CPU fallback for the HIP path")
+    L = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.sphip_abi_version.restype = C.c_int
+    L.sphip_kernel_name.restype = C.c_char_p
+    L.sphip_kernel_name.argtypes = [C.c_int]
+    L.sphip_create.restype = C.c_int
+    L.sphip_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.sphip_destroy.restype = None
+    L.sphip_destroy.argtypes = [vp]
+    L.sphip_last_error.restype = C.c_char_p
+    L.sphip_last_error.argtypes = [vp]
+    L.sphip_description.restype = C.c_char_p
+    L.sphip_description.argtypes = [vp]
+    L.sphip_set_scene.restype = C.c_int
+    L.sphip_set_scene.argtypes = [vp, vp, vp, sz]
+    L.sphip_render.restype = C.c_int
+    L.sphip_render.argtypes = [vp, vp, sz, sz, sz, C.c_uint64, C.c_int, C.c_int, vp, vp]
+    L.sphip_set_scene_device.restype = C.c_int
+    L.sphip_set_scene_device.argtypes = [vp, vp, vp, sz, vp]
+    L.sphip_render_device.restype = C.c_int
+    L.sphip_render_device.argtypes = [vp, vp, sz, C.POINTER(Shard), sz, sz, C.c_uint64, C.c_int, C.c_int, vp, vp, vp]
+    L.sphip_get_stats.restype = C.c_int
+    L.sphip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def kernel_variants():
+    """{name: id} of the scan-kernel variants the library exposes (id 0 = auto)."""
+    L = load()
+    out, i = {}, 0
+    while True:
+        n = L.sphip_kernel_name(i)
+        if n is None:
+            break
+        out[n.decode()] = i
+        i += 1
+    return out
+
+
+class Context:
+    """One sphip_t: a device, its cached buffers and its scene."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.sphip_create(device, C.byref(h))
+        if rc != 0:
+            raise SpathHipError(f"sphip_create({device}) failed [{rc}]: {self._L.sphip_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sphip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SpathHipError(f"{what} failed [{rc}]: {self._L.sphip_last_error(self._h).decode()}")
+
+    @property
+    def description(self) -> str:
+        return self._L.sphip_description(self._h).decode()
+
+    # host-pointer path -------------------------------------------------------------------------
+    def set_scene(self, tris, mats):
+        import numpy as np
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 12)
+        mats = np.ascontiguousarray(mats, dtype=np.float32).reshape(-1, 6)
+        if tris.shape[0] != mats.shape[0]:
+            raise ValueError("one material per triangle")
+        self._check(self._L.sphip_set_scene(self._h, tris.ctypes.data, mats.ctypes.data, tris.shape[0]), "sphip_set_scene")
+
+    def render(self, rays, w, h, n_samples, seed=1, mode=MODE_PT, flags=0, want_accum=False):
+        import numpy as np
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        if rays.shape[0] != w * h:
+            raise ValueError("rays must hold w*h entries")
+        out = np.zeros((w * h, 4), dtype=np.uint8)
+        acc = np.zeros((w * h, 3), dtype=np.float32) if want_accum else None
+        self._check(self._L.sphip_render(self._h, rays.ctypes.data, w, h, n_samples, seed, mode, flags,
+                                         out.ctypes.data, acc.ctypes.data if want_accum else None), "sphip_render")
+        return (out, acc) if want_accum else out
+
+    # device-resident path ----------------------------------------------------------------------
+    def set_scene_device(self, d_tris: int, d_mats: int, n_tris: int, stream: int = 0):
+        self._check(self._L.sphip_set_scene_device(self._h, d_tris, d_mats, n_tris, stream), "sphip_set_scene_device")
+
+    def render_device(self, d_rays: int, n_rays: int, n_samples: int, d_out_rgba: int, *, seed=1, mode=MODE_PT,
+                      flags=0, shard=None, image_width=0, d_out_accum: int = 0, stream: int = 0):
+        sh = None
+        if shard is not None:
+            sh = C.byref(Shard(*[int(v) for v in shard]))
+        self._check(self._L.sphip_render_device(self._h, d_rays, n_rays, sh, image_width, n_samples, seed, mode, flags,
+                                                d_out_rgba, d_out_accum or None, stream or None), "sphip_render_device")
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._check(self._L.sphip_get_stats(self._h, C.byref(s)), "sphip_get_stats")
+        return s.as_dict()

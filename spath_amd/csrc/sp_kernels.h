@@ -1,0 +1,178 @@
+// Kernels of the spath hot path for gfx950 (CDNA4): triangle repack, flat pass, path tracer.
+//
+// Work decomposition: one lane owns one pixel for the whole integrator
+// (samples are accumulated in the reference's order, cpu_renderer.cpp:74-76), a wavefront walks 64
+// paths in lock-step through the (wave-uniform) depth loop, and the closest-hit scan streams the
+// repacked triangle array once per (wave, bounce).
+#pragma once
+
+#include "sp_device_math.h"
+
+namespace sp {
+
+// scan record: 48 B = 3 x float4, produced by k_repack
+//   q0 = v0.x v0.y v0.z e1.x   q1 = e1.y e1.z e2.x e2.y   q2 = e2.z 0 0 0
+struct KArgs {
+	const float*  rays;        // n_rays * 6
+	const float4* scan;        // n_tris * 3
+	const float*  tris;        // n_tris * 12 (normals live at +9)
+	const float*  mats;        // n_tris * 6
+	uint32_t*     out_rgba;    // n_rays
+	float*        out_accum;   // n_rays * 3 or nullptr
+	unsigned long long* scans; // device counter
+	uint32_t n_rays, n_tris, n_samples, flags;
+	uint64_t seed;
+	uint64_t pixel_base, tile_px, tile_stride_px;
+	float inv_n;               // float(1.0/n_samples), cpu_renderer.cpp:77
+};
+
+// ---- repack: AoS geom::triangle -> scan records.  e1/e2 are the single float subtractions of
+// geom.h:200-201, hoisted out of the per-ray test (same bits).
+__global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, float4* __restrict__ scan, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float* t = tris + (size_t)i * 12;
+	const float v0x = t[0], v0y = t[1], v0z = t[2];
+	const float e1x = t[3] - v0x, e1y = t[4] - v0y, e1z = t[5] - v0z;
+	const float e2x = t[6] - v0x, e2y = t[7] - v0y, e2z = t[8] - v0z;
+	scan[(size_t)i * 3 + 0] = make_float4(v0x, v0y, v0z, e1x);
+	scan[(size_t)i * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
+	scan[(size_t)i * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+}
+
+SP_DEV uint64_t shard_pixel(const KArgs& a, uint32_t k) {
+	const uint64_t t = (uint64_t)k / a.tile_px;
+	return a.pixel_base + t * a.tile_stride_px + ((uint64_t)k - t * a.tile_px);
+}
+
+// ---- closest-hit scan, variant "rpl_sload": ray per lane, triangle index wave-uniform so the
+// records arrive through the scalar data path (s_load_dwordx4) and every VALU op reads them as
+// SGPR operands.  Semantics of cpu_renderer.cpp:36-49: ascending index, strict '<', skip idx_source.
+SP_DEV void scan_rpl_sload(const float4* __restrict__ scan, uint32_t n_tris, f3 o, f3 dir, int src,
+                           float& best_d, int& best_i) {
+	float bd = kMaxDist;
+	int bi = -1;
+	for (uint32_t j = 0; j < n_tris; ++j) {
+		const float4 q0 = scan[3 * j + 0], q1 = scan[3 * j + 1], q2 = scan[3 * j + 2];
+		const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+		const float d = ray_tri_strict(o, dir, v0, e1, e2);
+		const bool take = (d > 0.0f) && (d < bd) && ((int)j != src);
+		bd = take ? d : bd;
+		bi = take ? (int)j : bi;
+	}
+	best_d = bd;
+	best_i = bi;
+}
+
+template <int VARIANT>
+SP_DEV void closest_hit(const KArgs& a, f3 o, f3 dir, int src, float& best_d, int& best_i) {
+	scan_rpl_sload(a.scan, a.n_tris, o, dir, src, best_d, best_i);
+}
+
+SP_DEV void wave_add_scans(unsigned long long* ctr, uint32_t mine) {
+	// one atomic per wavefront
+	uint32_t v = mine;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	if ((threadIdx.x & 63u) == 0 && v) atomicAdd(ctr, (unsigned long long)v);
+}
+
+// ---- renderer::render_flat (cpu_renderer.cpp:81-101): nearest triangle's reflectance, no skip
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_flat(const KArgs a) {
+	const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+	const bool valid = k < a.n_rays;
+	const uint32_t kk = valid ? k : a.n_rays - 1;
+	const float* r = a.rays + (size_t)kk * 6;
+	const f3 o = mk3(r[0], r[1], r[2]), dir = mk3(r[3], r[4], r[5]);
+	float bd; int bi;
+	closest_hit<VARIANT>(a, o, dir, -1, bd, bi);
+	uint32_t px = 0;                                             // :89 RGBA{0,0,0,0}
+	if (bi >= 0) {
+		const float* m = a.mats + (size_t)bi * 6;
+		px = vec3_rgba(mk3(m[0], m[1], m[2]));                   // :96
+	}
+	if (valid) a.out_rgba[k] = px;
+	wave_add_scans(a.scans, valid ? 1u : 0u);
+}
+
+// ---- renderer::render (cpu_renderer.cpp:29-79): n_samples x (<=5 surface hits).
+// The recursion of render_step is run forward (store idx and cos(theta) per depth) and unwound
+// backward in the reference's own evaluation order  E + (((BRDF*rec)*cos)*(1/p))  (:67) -- the
+// shape the reference itself uses in its GLSL backend (render.comp:160-215).
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_pt(const KArgs a) {
+	const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+	const bool valid = k < a.n_rays;
+	const uint32_t kk = valid ? k : a.n_rays - 1;
+	const float* r = a.rays + (size_t)kk * 6;
+	const f3 po = mk3(r[0], r[1], r[2]), pdir = mk3(r[3], r[4], r[5]);
+	const uint32_t pixel = (uint32_t)shard_pixel(a, kk);
+	const bool reuse = (a.flags & 0x100u) != 0;
+
+	uint32_t my_scans = 0;
+	// optional primary-hit reuse: the primary ray is the same for every sample (:74-76)
+	float pd = 0.0f; int pi = -1;
+	if (reuse) { closest_hit<VARIANT>(a, po, pdir, -1, pd, pi); my_scans += valid ? 1u : 0u; }
+
+	f3 accum = mk3(0.0f, 0.0f, 0.0f);
+	for (uint32_t s = 0; s < a.n_samples; ++s) {
+		f3 o = po, dir = pdir;
+		int src = -1;
+		int idx0 = -1, idx1 = -1, idx2 = -1, idx3 = -1, idx4 = -1;
+		float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, c4 = 0.0f;
+		bool alive = valid;
+#pragma unroll 1
+		for (int depth = 0; depth < 5; ++depth) {                // :33 depth >= 5 -> black
+			if (__ballot(alive) == 0ull) break;
+			float bd; int bi;
+			if (depth == 0 && reuse) { bd = pd; bi = pi; }
+			else { closest_hit<VARIANT>(a, o, dir, src, bd, bi); my_scans += alive ? 1u : 0u; }
+			const bool hit = alive && (bi >= 0);                  // :51 miss -> black
+			if (hit) {
+				const float* tn = a.tris + (size_t)bi * 12 + 9;
+				f3 n = mk3(tn[0], tn[1], tn[2]);                  // :55
+				if (dot3(n, dir) > 0.0f) n = scale3(n, -1.0f);    // :56-57
+				double r1, r2;
+				philox_uniforms(a.seed, pixel, s, (uint32_t)depth, &r1, &r2);
+				const f3 nd = rand_unit_vec(n, r1, r2);           // :58
+				const float ct = dot3(nd, n);                     // :62
+				o = add3(o, scale3(dir, bd));                     // geom.h:218 point = pos + dir*d
+				dir = nd;
+				src = bi;
+				if (depth == 0) { idx0 = bi; c0 = ct; }
+				else if (depth == 1) { idx1 = bi; c1 = ct; }
+				else if (depth == 2) { idx2 = bi; c2 = ct; }
+				else if (depth == 3) { idx3 = bi; c3 = ct; }
+				else { idx4 = bi; c4 = ct; }
+			}
+			alive = hit;
+		}
+		// unwind: rec(depth) = E + (((BRDF * rec(depth+1)) * cos) * (1/p)), rec beyond the last hit = 0
+		f3 rec = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+		for (int depth = 4; depth >= 0; --depth) {
+			const int id = depth == 0 ? idx0 : depth == 1 ? idx1 : depth == 2 ? idx2 : depth == 3 ? idx3 : idx4;
+			const float ct = depth == 0 ? c0 : depth == 1 ? c1 : depth == 2 ? c2 : depth == 3 ? c3 : c4;
+			if (id >= 0) {
+				const float* m = a.mats + (size_t)id * 6;
+				const f3 brdf = scale3(mk3(m[0], m[1], m[2]), kInvPi);                     // :63
+				const f3 e = mk3(m[3], m[4], m[5]);
+				rec = add3(e, scale3(scale3(mul3(brdf, rec), ct), kInvP));                 // :67
+			}
+		}
+		accum = add3(accum, rec);                                // :75
+	}
+	accum = scale3(accum, a.inv_n);                              // :77
+	if (valid) {
+		a.out_rgba[k] = vec3_rgba(mk3(clamp01(accum.x), clamp01(accum.y), clamp01(accum.z)));  // :78
+		if (a.out_accum) {
+			a.out_accum[(size_t)k * 3 + 0] = accum.x;
+			a.out_accum[(size_t)k * 3 + 1] = accum.y;
+			a.out_accum[(size_t)k * 3 + 2] = accum.z;
+		}
+	}
+	wave_add_scans(a.scans, my_scans);
+}
+
+} // namespace sp

@@ -1,0 +1,276 @@
+// libspath_hip.so -- C ABI (include/spath_hip.h) over the gfx950 kernels in sp_kernels.h.
+//
+// Host side of the drop-in boundary: owns the device buffers (grow-only, like the reference's
+// OpenCL peer caches its cl::Buffers, src/cl_renderer.cpp:107-112), uploads what
+// renderer::render / render_flat are handed (src/renderer.h:31-32), launches, reads back.
+// No exception crosses this boundary; every failure becomes a status + sphip_last_error().
+#include "spath_hip.h"
+#include "sp_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+};
+
+} // namespace
+
+struct sphip_ctx {
+	int device = 0;
+	hipStream_t own_stream = nullptr;       // host-pointer path
+	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
+	DevBuf tris, mats, scan, rays, rgba, accum, counter;
+	size_t n_tris = 0;
+	bool have_scene = false;
+	bool have_render = false, timed_upload = false, timed_download = false;
+	sphip_stats stats{};
+	std::string err;
+	std::string desc;
+	hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+int fail(sphip_ctx* c, int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf; else g_create_error = buf;
+	return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess)                                                                    \
+			return fail((c), SPHIP_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
+	if (bytes <= b.cap && b.p) return SPHIP_OK;
+	if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+	const size_t want = bytes < 256 ? 256 : bytes;
+	HIP_TRY(c, hipMalloc(&b.p, want));
+	b.cap = want;
+	return SPHIP_OK;
+}
+
+constexpr int kNumVariants = 1;
+const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload" };
+
+int pick_variant(int flags, size_t /*n_tris*/) {
+	const int v = flags & SPHIP_KERNEL_MASK;
+	if (v >= 1 && v <= kNumVariants) return v;
+	return 1;
+}
+
+int repack(sphip_ctx* c, hipStream_t st) {
+	const uint32_t n = (uint32_t)c->n_tris;
+	int rc = ensure(c, c->scan, c->n_tris * 48);
+	if (rc) return rc;
+	hipLaunchKernelGGL(sp::k_repack, dim3((n + 255) / 256), dim3(256), 0, st,
+	                   (const float*)c->tris.p, (float4*)c->scan.p, n);
+	HIP_TRY(c, hipGetLastError());
+	c->have_scene = true;
+	return SPHIP_OK;
+}
+
+int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_shard* shard, size_t /*image_width*/,
+                  size_t n_samples, uint64_t seed, int mode, int flags, void* d_rgba, void* d_accum, hipStream_t st) {
+	if (!c->have_scene) return fail(c, SPHIP_E_STATE, "render called before a scene was set");
+	if (!d_rays || !d_rgba) return fail(c, SPHIP_E_INVALID, "null ray or output pointer");
+	if (n_rays == 0 || n_rays > 0xffffffffull) return fail(c, SPHIP_E_INVALID, "n_rays %zu out of range", n_rays);
+	if (mode != SPHIP_MODE_FLAT && mode != SPHIP_MODE_PT) return fail(c, SPHIP_E_INVALID, "unknown mode %d", mode);
+	if (mode == SPHIP_MODE_PT && (n_samples == 0 || n_samples > 0x7fffffffull))
+		return fail(c, SPHIP_E_INVALID, "n_samples must be in [1, 2^31) (the reference divides by it, cpu_renderer.cpp:77)");
+	int rc = ensure(c, c->counter, sizeof(unsigned long long));
+	if (rc) return rc;
+
+	sp::KArgs a{};
+	a.rays = (const float*)d_rays;
+	a.scan = (const float4*)c->scan.p;
+	a.tris = (const float*)c->tris.p;
+	a.mats = (const float*)c->mats.p;
+	a.out_rgba = (uint32_t*)d_rgba;
+	a.out_accum = (float*)d_accum;
+	a.scans = (unsigned long long*)c->counter.p;
+	a.n_rays = (uint32_t)n_rays;
+	a.n_tris = (uint32_t)c->n_tris;
+	a.n_samples = (uint32_t)n_samples;
+	a.flags = (uint32_t)flags;
+	a.seed = seed;
+	if (shard) {
+		if (shard->tile_px == 0) return fail(c, SPHIP_E_INVALID, "shard.tile_px must be > 0");
+		a.pixel_base = shard->pixel_base; a.tile_px = shard->tile_px; a.tile_stride_px = shard->tile_stride_px;
+	} else {
+		a.pixel_base = 0; a.tile_px = n_rays; a.tile_stride_px = 0;
+	}
+	a.inv_n = (float)(1.0 / (double)(n_samples ? n_samples : 1));      // cpu_renderer.cpp:77
+
+	const int variant = pick_variant(flags, c->n_tris);
+	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(unsigned long long), st));
+	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
+	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
+	if (mode == SPHIP_MODE_FLAT) hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
+	else                         hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipEventRecord(c->ev_k1, st));
+	c->have_render = true;
+	c->last_stream = st;
+	c->stats.n_tris = c->n_tris;
+	c->stats.n_pixels = n_rays;
+	c->stats.kernel_variant = (uint32_t)variant;
+	c->stats.n_launches = 1;
+	return SPHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sphip_abi_version(void) { return SPHIP_ABI_VERSION; }
+
+const char* sphip_kernel_name(int variant) {
+	if (variant < 0 || variant > kNumVariants) return nullptr;
+	return kVariantNames[variant];
+}
+
+int sphip_create(int device_id, sphip_t** out) {
+	if (!out) return fail(nullptr, SPHIP_E_INVALID, "out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail(nullptr, SPHIP_E_DEVICE, "no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+	if (device_id < 0 || device_id >= n) return fail(nullptr, SPHIP_E_INVALID, "device %d out of range [0,%d)", device_id, n);
+	sphip_ctx* c = new (std::nothrow) sphip_ctx();
+	if (!c) return fail(nullptr, SPHIP_E_DEVICE, "out of host memory");
+	c->device = device_id;
+	hipDeviceProp_t prop;
+	if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+	    (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+		fail(nullptr, SPHIP_E_DEVICE, "device %d init failed: %s", device_id, hipGetErrorString(e));
+		delete c;
+		return SPHIP_E_DEVICE;
+	}
+	hipEvent_t* evs[6] = { &c->ev_k0, &c->ev_k1, &c->ev_u0, &c->ev_u1, &c->ev_d0, &c->ev_d1 };
+	for (auto ev : evs) {
+		if ((e = hipEventCreate(ev)) != hipSuccess) {
+			fail(nullptr, SPHIP_E_DEVICE, "hipEventCreate failed: %s", hipGetErrorString(e));
+			sphip_destroy(c);
+			return SPHIP_E_DEVICE;
+		}
+	}
+	char d[256];
+	snprintf(d, sizeof d, "HIP - Path Tracing (%s, %s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+	c->desc = d;
+	*out = c;
+	return SPHIP_OK;
+}
+
+void sphip_destroy(sphip_t* c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+	DevBuf* bufs[7] = { &c->tris, &c->mats, &c->scan, &c->rays, &c->rgba, &c->accum, &c->counter };
+	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
+	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
+	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
+	if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+	delete c;
+}
+
+const char* sphip_last_error(const sphip_t* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+const char* sphip_description(const sphip_t* c) { return c ? c->desc.c_str() : "HIP - Path Tracing"; }
+
+int sphip_set_scene(sphip_t* c, const float* tris, const float* mats, size_t n_tris) {
+	if (!c) return SPHIP_E_INVALID;
+	if (!tris || !mats || n_tris == 0 || n_tris > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad scene arguments (n_tris=%zu)", n_tris);
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc;
+	if ((rc = ensure(c, c->tris, n_tris * 48)) || (rc = ensure(c, c->mats, n_tris * 24))) return rc;
+	c->n_tris = n_tris;
+	HIP_TRY(c, hipMemcpyAsync(c->tris.p, tris, n_tris * 48, hipMemcpyHostToDevice, c->own_stream));
+	HIP_TRY(c, hipMemcpyAsync(c->mats.p, mats, n_tris * 24, hipMemcpyHostToDevice, c->own_stream));
+	if ((rc = repack(c, c->own_stream))) return rc;
+	HIP_TRY(c, hipStreamSynchronize(c->own_stream));   // tris/mats are borrowed: do not outlive the call
+	return SPHIP_OK;
+}
+
+int sphip_set_scene_device(sphip_t* c, const void* d_tris, const void* d_mats, size_t n_tris, void* stream) {
+	if (!c) return SPHIP_E_INVALID;
+	if (!d_tris || !d_mats || n_tris == 0 || n_tris > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad scene arguments (n_tris=%zu)", n_tris);
+	HIP_TRY(c, hipSetDevice(c->device));
+	hipStream_t st = (hipStream_t)stream;
+	int rc;
+	if ((rc = ensure(c, c->tris, n_tris * 48)) || (rc = ensure(c, c->mats, n_tris * 24))) return rc;
+	c->n_tris = n_tris;
+	HIP_TRY(c, hipMemcpyAsync(c->tris.p, d_tris, n_tris * 48, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(c->mats.p, d_mats, n_tris * 24, hipMemcpyDeviceToDevice, st));
+	return repack(c, st);
+}
+
+int sphip_render_device(sphip_t* c, const void* d_rays, size_t n_rays, const sphip_shard* shard, size_t image_width,
+                        size_t n_samples, uint64_t seed, int mode, int flags, void* d_out_rgba, void* d_out_accum, void* stream) {
+	if (!c) return SPHIP_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	c->timed_upload = c->timed_download = false;
+	return launch_render(c, d_rays, n_rays, shard, image_width, n_samples, seed, mode, flags, d_out_rgba, d_out_accum, (hipStream_t)stream);
+}
+
+int sphip_render(sphip_t* c, const float* rays, size_t w, size_t h, size_t n_samples, uint64_t seed, int mode, int flags,
+                 uint8_t* out_rgba, float* out_accum) {
+	if (!c) return SPHIP_E_INVALID;
+	if (!rays || !out_rgba || w == 0 || h == 0) return fail(c, SPHIP_E_INVALID, "bad render arguments (w=%zu h=%zu)", w, h);
+	HIP_TRY(c, hipSetDevice(c->device));
+	const size_t n = w * h;
+	hipStream_t st = c->own_stream;
+	int rc;
+	if ((rc = ensure(c, c->rays, n * 24)) || (rc = ensure(c, c->rgba, n * 4))) return rc;
+	if (out_accum && (rc = ensure(c, c->accum, n * 12))) return rc;
+	HIP_TRY(c, hipEventRecord(c->ev_u0, st));
+	HIP_TRY(c, hipMemcpyAsync(c->rays.p, rays, n * 24, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipEventRecord(c->ev_u1, st));
+	if ((rc = launch_render(c, c->rays.p, n, nullptr, w, n_samples, seed, mode, flags, c->rgba.p, out_accum ? c->accum.p : nullptr, st))) return rc;
+	HIP_TRY(c, hipEventRecord(c->ev_d0, st));
+	HIP_TRY(c, hipMemcpyAsync(out_rgba, c->rgba.p, n * 4, hipMemcpyDeviceToHost, st));
+	if (out_accum) HIP_TRY(c, hipMemcpyAsync(out_accum, c->accum.p, n * 12, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipEventRecord(c->ev_d1, st));
+	HIP_TRY(c, hipStreamSynchronize(st));           // blocking, like every reference backend (main.cpp:70-83)
+	c->timed_upload = c->timed_download = true;
+	return SPHIP_OK;
+}
+
+int sphip_get_stats(sphip_t* c, sphip_stats* out) {
+	if (!c || !out) return SPHIP_E_INVALID;
+	if (!c->have_render) return fail(c, SPHIP_E_STATE, "no render has been issued yet");
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipEventSynchronize(c->ev_k1));
+	float ms = 0.0f;
+	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_k0, c->ev_k1));
+	c->stats.kernel_ms = ms;
+	c->stats.upload_ms = c->stats.download_ms = 0.0;
+	if (c->timed_upload) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_u0, c->ev_u1)); c->stats.upload_ms = ms; }
+	if (c->timed_download) { HIP_TRY(c, hipEventSynchronize(c->ev_d1)); HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_d0, c->ev_d1)); c->stats.download_ms = ms; }
+	unsigned long long scans = 0;
+	HIP_TRY(c, hipMemcpyAsync(&scans, c->counter.p, sizeof scans, hipMemcpyDeviceToHost, c->last_stream));
+	HIP_TRY(c, hipStreamSynchronize(c->last_stream));
+	c->stats.scans_executed = scans;
+	*out = c->stats;
+	return SPHIP_OK;
+}
+
+} // extern "C"
