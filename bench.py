@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mray/s (primary x spp x bounces) of the path-tracing hot path on MI355X.
+
+A step = one full render (renderer::render semantics, reference src/cpu_renderer.cpp:29-79) of
+BASELINE.json configs[2]: closed-room scene with 10,000 triangles, 1920x1080, 256 spp, 5 bounces,
+all inputs (rays, triangles, materials) resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the same image is split into pixel-row tiles dealt round-robin to the ranks (strong
+scaling; spath_amd/dist.py); each step ends with one RCCL gather of the RGBA8 tiles to rank 0.
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus `roofline` and
+`cpu_baseline`:
+  roofline.achieved = scans_executed x n_tris x 48 B / kernel time  (algorithmic bytes the
+  reference's scan reads per ray, sizeof(geom::triangle), geom.h:185-190), kernel time from HIP
+  events on the launch stream.  It is an *effective* bandwidth: LDS/L2 reuse lets it exceed the
+  HBM peak, which is why valu_frac (52 flop per ray-triangle test against the 157.3 TFLOP/s
+  FP32 vector peak) is printed next to it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+BYTES_PER_TEST = 48          # sizeof(geom::triangle)
+FLOPS_PER_TEST = 52
+
+
+def cpu_baseline(tris, mats, args):
+    """The reference's cpu_renderer timed on this box's host cores on a bounded sample of the same scene."""
+    import numpy as np
+    from oracle import oracle as O
+    from spath_amd import view
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    w, h, spp = args.cpu_w, args.cpu_h, args.cpu_spp
+    nominal = w * h * spp * 5
+    if O.have_ref():
+        _, info = O.ref_run("render", w, h, spp, tris, mats, threads=cores, return_info=True)
+        secs, kind = info["seconds"], "reference"
+        what = "unmodified reference cpu_renderer (oracle/_ref/spath_ref)"
+    else:
+        rays = view.Camera(w, h).get_viewport()
+        O.lib()
+        t0 = time.perf_counter()
+        O.render_mt(rays, w, h, tris, mats, spp, cores, cores)
+        secs, kind = time.perf_counter() - t0, "port"
+        what = "C restatement of cpu_renderer (oracle/liboracle.so)"
+    return {"value": nominal / secs / 1e6, "unit": "Mray/s", "cores": cores, "kind": kind,
+            "seconds": round(secs, 3),
+            "sample": f"{what}, same scene ({tris.shape[0]} triangles), {w}x{h} x {spp} spp x 5 bounces, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--tris", type=int, default=10000)
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--kernel", type=str, default="auto", help="scan kernel variant (see sphip_kernel_name)")
+    ap.add_argument("--primary-reuse", action="store_true", help="scan the primary ray once per pixel (fewer scans; off for roofline runs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-w", type=int, default=192)
+    ap.add_argument("--cpu-h", type=int, default=108)
+    ap.add_argument("--cpu-spp", type=int, default=16)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from spath_amd import capi, scene, view
+    from spath_amd.dist import RowTilePlan, ShardedRenderer, gather_to_root
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    W, H, SPP, NT = args.width, args.height, args.spp, args.tris
+    tris, mats = scene.closed_room(NT)
+    rays = view.Camera(W, H).get_viewport()
+    plan = RowTilePlan(W, H, world, args.tile_rows)
+
+    ctx = capi.Context(local_rank)
+    variants = capi.kernel_variants()
+    if args.kernel not in variants:
+        raise SystemExit(f"unknown --kernel {args.kernel}; have {sorted(variants)}")
+    flags = variants[args.kernel] | (capi.FLAG_PRIMARY_REUSE if args.primary_reuse else 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_tris, d_mats = torch.from_numpy(tris).to(dev), torch.from_numpy(mats).to(dev)
+    ctx.set_scene_device(d_tris.data_ptr(), d_mats.data_ptr(), NT, stream)
+    shard = ShardedRenderer(ctx, plan, rank, rays, dev)
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    scans_total = 0
+    image = None
+
+    def step(i_timed=None):
+        nonlocal image
+        if i_timed is not None:
+            ev[i_timed][0].record()
+        local = shard.render(SPP, seed=1, mode=capi.MODE_PT, flags=flags, stream=stream)
+        if i_timed is not None:
+            ev[i_timed][1].record()
+        image = gather_to_root(local, plan, rank) if world > 1 else local
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        scans_total += 0
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()                       # figures of the last launch on this rank
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([float(st["scans_executed"]), max(kernel_ms) if kernel_ms else 0.0], dtype=torch.float64, device=dev)
+        s_sum = s.clone(); dist.all_reduce(s_sum, op=dist.ReduceOp.SUM)
+        s_max = s.clone(); dist.all_reduce(s_max, op=dist.ReduceOp.MAX)
+        scans_per_step, kern_ms_max = float(s_sum[0].item()), float(s_max[1].item())
+    else:
+        scans_per_step, kern_ms_max = float(st["scans_executed"]), (sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0)
+
+    if rank == 0:
+        nominal = W * H * SPP * 5
+        ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+        value = nominal * args.steps / elapsed / 1e6
+        # dominant kernel = the path-trace kernel (one launch per step per rank); average launch duration
+        avg_kernel_s = (sum(kernel_ms) / len(kernel_ms) * 1e-3) if kernel_ms else float("nan")
+        my_scans = float(st["scans_executed"])
+        achieved = my_scans * NT * BYTES_PER_TEST / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{NT}tris_{W}x{H}x{SPP}_g{world}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mray/s (primary x spp x bounces)",
+            "value": round(value, 3),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"closed-room {NT} triangles, {W}x{H}, {SPP} spp, 5 bounces (BASELINE.json configs[2])"
+                            if (NT, W, H, SPP) == (10000, 1920, 1080, 256) else f"closed-room {NT} triangles, {W}x{H}, {SPP} spp, 5 bounces",
+                "n_tris": NT, "width": W, "height": H, "spp": SPP, "bounces": 5,
+                "sharding": "whole image on 1 GPU" if world == 1 else f"{args.tile_rows}-row tiles round-robin over {world} GPUs + RCCL gather",
+                "kernel": capi.load().sphip_kernel_name(st["kernel_variant"]).decode(),
+                "primary_reuse": bool(args.primary_reuse),
+                "arithmetic": "strict (no FMA contraction, IEEE divide): bit-identical to the CPU oracle",
+            },
+            "scans_per_step": scans_per_step,
+            "nominal_rays_per_step": nominal,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel": "k_pt",
+                "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
+                "algorithmic_bytes_per_launch": my_scans * NT * BYTES_PER_TEST,
+                "note": "effective (logical-stream) bandwidth of rank 0's launch; exceeds HBM peak because triangles are reused from LDS/L2",
+                "tests_per_s": round(my_scans * NT / avg_kernel_s, 1),
+                "valu_frac": round(my_scans * NT * FLOPS_PER_TEST / avg_kernel_s / (FP32_PEAK_TFLOPS * 1e12), 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tris, mats, args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

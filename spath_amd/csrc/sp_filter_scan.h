@@ -1,0 +1,329 @@
+// Two-stage closest-hit scan ("rpl_filter"): a cheap CONSERVATIVE reject per (ray, triangle),
+// the reference's exact Moeller-Trumbore only for the rare survivors.  Bit-identical results.
+//
+// Stage 1 (every pair, 11 VALU): is the ray outside the slab spanned by the two lines through v0 and
+// through v1 that run parallel to edge2?  With w = unit(e2), P = pos x dir (ray moment, per ray),
+// M0 = w x v0, M1 = w x v1 (per triangle):
+//     g0 = (pos - v0) . (dir x w) = w.P - dir.M0        g1 = (pos - v1) . (dir x w) = w.P - dir.M1
+// g0 is the reference's s.h (geom.h:208) up to the factor |e2|, and g0 - g1 its a (geom.h:203).
+// geom::ray_intersect accepts only if u = f*(s.h) lies in [0,1] (geom.h:209), i.e. only if g0 and g1
+// have opposite signs up to rounding.  So: reject when they have the same sign and the smaller
+// magnitude exceeds an error margin Dq:   |med3(g0, g1, 0)| > Dq.
+//
+// Why this never rejects a pair the reference accepts (DESIGN.md section 4 has the full derivation):
+// let sh_f, a_f be the floats the strict evaluation produces.  Accepting needs 0 <= fl(fl(1/a_f)*sh_f)
+// <= 1, hence sh_f and (a_f - sh_f) have the same sign, or one of them is below 3u*|e1||dir||e2|.
+// Every quantity here is a sum of at most 9 products of bounded inputs, so with u = 2^-24
+//     |g0*|e2| - sh_f| and |(-g1)*|e2| - (a_f - sh_f)|  <=  36 u |e2| |dir| (|pos| + |v0| + |v1|)
+// (strict evaluation 7.6u + filter FMA chain 6u + rounding of P, M, w 7u + e1 = fl(v1-v0) 1.8u + the
+// relative slack of the u-comparisons 3u, each times the magnitude bound).  If g0, g1 share a sign and
+// both exceed twice that bound, sh_f and a_f - sh_f provably have opposite signs and exceed the bound:
+// the reference rejects.  Dq is set to 2^-16 |dir|_1 (|pos|_1 + 2 Rv) >= 2 * 36u * (...) with the
+// 1-norms over-estimating the 2-norms and Rv = max vertex norm of the scene; it is per ray, exact
+// |pos| and |dir| of that ray, so there is no assumption on where rays start.  The compare is the
+// NaN-safe !(x > Dq): any overflow or NaN in stage 1 makes the pair a survivor.
+//
+// Stage 2: survivors (about 1 % of pairs for small triangles) are queued per lane in LDS and run
+// through ray_tri_strict (sp_device_math.h) in index order at the end of each triangle tile, so the
+// update rule "first strictly smaller d wins" (cpu_renderer.cpp:44) is preserved.
+#pragma once
+
+#include "sp_kernels.h"
+
+namespace sp {
+
+constexpr int kQCap = 32;   // queue entries per lane (u16: slot<<8 | index in tile)
+
+// filter record: 48 B = 3 x float4, produced by k_repack_filter
+//   q0 = w.x w.y w.z M0.x   q1 = M0.y M0.z M1.x M1.y   q2 = M1.z 0 0 0
+__global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__ tris, float4* __restrict__ filt,
+                                                      unsigned int* __restrict__ bounds, uint32_t n, uint32_t n_padded) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_padded) return;
+	if (i >= n) {   // padding: w = M = 0 -> g0 = g1 = 0 -> survivor; never queued because the loop stops at n rounded up to 4,
+		            // and the exact stage rejects the zero exact record (a = 0)
+		const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		filt[(size_t)i * 3 + 0] = z; filt[(size_t)i * 3 + 1] = z; filt[(size_t)i * 3 + 2] = z;
+		return;
+	}
+	const float* t = tris + (size_t)i * 12;
+	const double v0x = t[0], v0y = t[1], v0z = t[2], v1x = t[3], v1y = t[4], v1z = t[5];
+	// e2 exactly as the reference rounds it (geom.h:201), then normalised in double
+	const double e2x = (double)(t[6] - t[0]), e2y = (double)(t[7] - t[1]), e2z = (double)(t[8] - t[2]);
+	const double len = sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
+	const float wx = (float)(e2x / len), wy = (float)(e2y / len), wz = (float)(e2z / len);   // NaN for a degenerate edge: always survives
+	const double dwx = wx, dwy = wy, dwz = wz;
+	const float m0x = (float)(dwy * v0z - dwz * v0y), m0y = (float)(dwz * v0x - dwx * v0z), m0z = (float)(dwx * v0y - dwy * v0x);
+	const float m1x = (float)(dwy * v1z - dwz * v1y), m1y = (float)(dwz * v1x - dwx * v1z), m1z = (float)(dwx * v1y - dwy * v1x);
+	filt[(size_t)i * 3 + 0] = make_float4(wx, wy, wz, m0x);
+	filt[(size_t)i * 3 + 1] = make_float4(m0y, m0z, m1x, m1y);
+	filt[(size_t)i * 3 + 2] = make_float4(m1z, 0.0f, 0.0f, 0.0f);
+	// scene bound Rv >= every vertex norm, as 1-norms (>= 2-norm); non-negative floats order like their bit patterns;
+	// a NaN or inf coordinate yields a bit pattern >= inf, which turns the filter off in the kernels
+	float r = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const float s = fabsf(t[3 * k]) + fabsf(t[3 * k + 1]) + fabsf(t[3 * k + 2]);
+		r = (s > r || s != s) ? s : r;
+	}
+	atomicMax(bounds, __float_as_uint(r) & 0x7fffffffu);
+}
+
+template <int R>
+struct RaySlots {
+	f3 o[R], dir[R];
+	int src[R];
+	bool act[R];
+};
+
+// exact closest-hit over the index range [lo, hi) through the scalar path; used on queue overflow
+template <int R>
+SP_DEV void exact_range(const float4* __restrict__ scan, uint32_t lo, uint32_t hi, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
+	for (uint32_t j = lo; j < hi; ++j) {
+		const float4 q0 = scan[3 * j + 0], q1 = scan[3 * j + 1], q2 = scan[3 * j + 2];
+		const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			const float d = ray_tri_strict(s.o[r], s.dir[r], v0, e1, e2);
+			const bool take = (d > 0.0f) && (d < bd[r]) && ((int)j != s.src[r]);
+			bd[r] = take ? d : bd[r];
+			bi[r] = take ? (int)j : bi[r];
+		}
+	}
+}
+
+// Closest hit for the R rays of every lane.  Block-uniform call (barriers inside).
+template <int R>
+SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
+	__shared__ float4 sm[2 * kTileQ];
+	__shared__ unsigned short qs[kQCap * 256];   // [entry][thread]
+	const uint32_t tid = threadIdx.x;
+	const uint32_t n_tris = a.n_tris;
+	const uint32_t ntiles = (n_tris + kTile - 1) / kTile;
+
+	f3 P[R];
+	float Dq[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		P[r] = cross3(s.o[r], s.dir[r]);
+		const float dn = fabsf(s.dir[r].x) + fabsf(s.dir[r].y) + fabsf(s.dir[r].z);
+		const float on = fabsf(s.o[r].x) + fabsf(s.o[r].y) + fabsf(s.o[r].z);
+		const float m = 0x1p-16f * 1.01f * dn * (on + 2.0f * rv);
+		// inactive slot: margin -1 -> "|m| > -1" always true -> always rejected.  A non-finite margin
+		// (huge or NaN inputs) fails the '>' test for every pair -> everything survives -> exact path.
+		Dq[r] = s.act[r] ? m : -1.0f;
+		bd[r] = kMaxDist;
+		bi[r] = -1;
+	}
+
+	float4 p0 = filt[tid], p1 = filt[256 + tid], p2 = filt[512 + tid];
+	__syncthreads();
+	sm[tid] = p0; sm[256 + tid] = p1; sm[512 + tid] = p2;
+	__syncthreads();
+	for (uint32_t t = 0; t < ntiles; ++t) {
+		const float4* cur = sm + (t & 1u) * kTileQ;
+		const bool more = (t + 1 < ntiles);
+		const float4* nsrc = filt + (size_t)(more ? t + 1 : t) * kTileQ;
+		p0 = nsrc[tid]; p1 = nsrc[256 + tid]; p2 = nsrc[512 + tid];
+		const uint32_t left = n_tris - t * kTile;
+		const uint32_t cnt = left < (uint32_t)kTile ? left : (uint32_t)kTile;
+		const uint32_t base = t * kTile;
+		uint32_t qn = 0;           // entries queued by this lane in this tile
+		bool ovf = false;
+#pragma unroll 2
+		for (uint32_t j = 0; j < cnt; ++j) {
+			const float4 q0 = cur[3 * j + 0], q1 = cur[3 * j + 1], q2 = cur[3 * j + 2];
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				float A = q0.x * P[r].x;
+				A = __builtin_fmaf(q0.y, P[r].y, A);
+				A = __builtin_fmaf(q0.z, P[r].z, A);
+				float g0 = __builtin_fmaf(-s.dir[r].x, q0.w, A);
+				g0 = __builtin_fmaf(-s.dir[r].y, q1.x, g0);
+				g0 = __builtin_fmaf(-s.dir[r].z, q1.y, g0);
+				float g1 = __builtin_fmaf(-s.dir[r].x, q1.z, A);
+				g1 = __builtin_fmaf(-s.dir[r].y, q1.w, g1);
+				g1 = __builtin_fmaf(-s.dir[r].z, q2.x, g1);
+				const float m = __builtin_amdgcn_fmed3f(g0, g1, 0.0f);
+				if (!(fabsf(m) > Dq[r])) {                 // survivor (rare): queue it
+					if (qn < (uint32_t)kQCap) qs[qn * 256 + tid] = (unsigned short)((r << 8) | j);
+					else ovf = true;
+					qn += (qn < (uint32_t)kQCap) ? 1u : 0u;
+				}
+			}
+		}
+		// ---- stage 2: exact tests of this tile's survivors, in queue (= index) order
+		if (__builtin_expect(__any(ovf), 0)) {
+			// some lane overflowed its queue: the whole wave re-scans the tile exactly (rare: scenes made of
+			// triangles so large that most rays cross their slabs)
+			exact_range<R>(a.scan, base, base + cnt, s, bd, bi);
+		} else {
+			for (uint32_t e = 0; __any(e < qn); ++e) {
+				if (e < qn) {
+					const uint32_t ent = qs[e * 256 + tid];
+					const int slot = (int)(ent >> 8);
+					const uint32_t idx = base + (ent & 0xffu);
+					f3 o = s.o[0], dir = s.dir[0];
+					int src = s.src[0];
+#pragma unroll
+					for (int r = 1; r < R; ++r) if (slot == r) { o = s.o[r]; dir = s.dir[r]; src = s.src[r]; }
+					const float4 x0 = a.scan[3 * idx + 0], x1 = a.scan[3 * idx + 1], x2 = a.scan[3 * idx + 2];
+					const float d = ray_tri_strict(o, dir, mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+#pragma unroll
+					for (int r = 0; r < R; ++r) {
+						const bool take = (slot == r) && (d > 0.0f) && (d < bd[r]) && ((int)idx != src);
+						bd[r] = take ? d : bd[r];
+						bi[r] = take ? (int)idx : bi[r];
+					}
+				}
+			}
+		}
+		float4* nxt = sm + ((t + 1) & 1u) * kTileQ;
+		nxt[tid] = p0; nxt[256 + tid] = p1; nxt[512 + tid] = p2;
+		__syncthreads();
+	}
+}
+
+// ---- renderer::render_flat with the filter scan; R pixels per lane
+template <int R>
+__global__ void __launch_bounds__(256) k_flat_filter(const KArgs a, const float4* __restrict__ filt, const unsigned int* __restrict__ bounds) {
+	const float rv = __uint_as_float(bounds[0]);
+	const uint32_t tid = threadIdx.x;
+	RaySlots<R> s;
+	uint32_t k[R];
+	bool valid[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		k[r] = blockIdx.x * (256u * R) + r * 256u + tid;
+		valid[r] = k[r] < a.n_rays;
+		const uint32_t kk = valid[r] ? k[r] : a.n_rays - 1;
+		const float* p = a.rays + (size_t)kk * 6;
+		s.o[r] = mk3(p[0], p[1], p[2]); s.dir[r] = mk3(p[3], p[4], p[5]);
+		s.src[r] = -1; s.act[r] = valid[r];
+	}
+	float bd[R]; int bi[R];
+	scan_filter<R>(a, filt, rv, s, bd, bi);
+	uint32_t nsc = 0;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		uint32_t px = 0;
+		if (bi[r] >= 0) {
+			const float* m = a.mats + (size_t)bi[r] * 6;
+			px = vec3_rgba(mk3(m[0], m[1], m[2]));
+		}
+		if (valid[r]) { a.out_rgba[k[r]] = px; nsc++; }
+	}
+	wave_add_scans(a.scans, nsc);
+}
+
+// ---- renderer::render with the filter scan; R pixels per lane, all R paths advance in lock-step
+template <int R>
+__global__ void __launch_bounds__(256) k_pt_filter(const KArgs a, const float4* __restrict__ filt, const unsigned int* __restrict__ bounds) {
+	const float rv = __uint_as_float(bounds[0]);
+	const uint32_t tid = threadIdx.x;
+	uint32_t k[R], pixel[R];
+	bool valid[R];
+	const float* prim[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		k[r] = blockIdx.x * (256u * R) + r * 256u + tid;
+		valid[r] = k[r] < a.n_rays;
+		const uint32_t kk = valid[r] ? k[r] : a.n_rays - 1;
+		prim[r] = a.rays + (size_t)kk * 6;
+		pixel[r] = (uint32_t)shard_pixel(a, kk);
+	}
+	const bool reuse = (a.flags & 0x100u) != 0;
+	uint32_t my_scans = 0;
+	float pd[R]; int pi[R];
+	if (reuse) {
+		RaySlots<R> s;
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			s.o[r] = mk3(prim[r][0], prim[r][1], prim[r][2]); s.dir[r] = mk3(prim[r][3], prim[r][4], prim[r][5]);
+			s.src[r] = -1; s.act[r] = valid[r];
+			my_scans += valid[r] ? 1u : 0u;
+		}
+		scan_filter<R>(a, filt, rv, s, pd, pi);
+	}
+
+	f3 accum[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) accum[r] = mk3(0.0f, 0.0f, 0.0f);
+
+	for (uint32_t smp = 0; smp < a.n_samples; ++smp) {
+		RaySlots<R> s;
+		int hidx[R][5];
+		float hcos[R][5];
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			s.o[r] = mk3(prim[r][0], prim[r][1], prim[r][2]); s.dir[r] = mk3(prim[r][3], prim[r][4], prim[r][5]);
+			s.src[r] = -1; s.act[r] = valid[r];
+#pragma unroll
+			for (int d = 0; d < 5; ++d) { hidx[r][d] = -1; hcos[r][d] = 0.0f; }
+		}
+#pragma unroll 1
+		for (int depth = 0; depth < 5; ++depth) {
+			bool any_alive = false;
+#pragma unroll
+			for (int r = 0; r < R; ++r) any_alive |= s.act[r];
+			if (!__syncthreads_or(any_alive ? 1 : 0)) break;
+			float bd[R]; int bi[R];
+			if (depth == 0 && reuse) {
+#pragma unroll
+				for (int r = 0; r < R; ++r) { bd[r] = pd[r]; bi[r] = pi[r]; }
+			} else {
+				scan_filter<R>(a, filt, rv, s, bd, bi);
+#pragma unroll
+				for (int r = 0; r < R; ++r) my_scans += s.act[r] ? 1u : 0u;
+			}
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				const bool hit = s.act[r] && (bi[r] >= 0);
+				if (hit) {
+					const float* tn = a.tris + (size_t)bi[r] * 12 + 9;
+					f3 n = mk3(tn[0], tn[1], tn[2]);
+					if (dot3(n, s.dir[r]) > 0.0f) n = scale3(n, -1.0f);
+					double r1, r2;
+					philox_uniforms(a.seed, pixel[r], smp, (uint32_t)depth, &r1, &r2);
+					const f3 nd = rand_unit_vec(n, r1, r2);
+					const float ct = dot3(nd, n);
+					s.o[r] = add3(s.o[r], scale3(s.dir[r], bd[r]));
+					s.dir[r] = nd;
+					s.src[r] = bi[r];
+#pragma unroll
+					for (int d = 0; d < 5; ++d) if (depth == d) { hidx[r][d] = bi[r]; hcos[r][d] = ct; }
+				}
+				s.act[r] = hit;
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			f3 rec = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+			for (int d = 4; d >= 0; --d) {
+				if (hidx[r][d] >= 0) {
+					const float* m = a.mats + (size_t)hidx[r][d] * 6;
+					const f3 brdf = scale3(mk3(m[0], m[1], m[2]), kInvPi);
+					const f3 e = mk3(m[3], m[4], m[5]);
+					rec = add3(e, scale3(scale3(mul3(brdf, rec), hcos[r][d]), kInvP));
+				}
+			}
+			accum[r] = add3(accum[r], rec);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const f3 acc = scale3(accum[r], a.inv_n);
+		if (valid[r]) {
+			a.out_rgba[k[r]] = vec3_rgba(mk3(clamp01(acc.x), clamp01(acc.y), clamp01(acc.z)));
+			if (a.out_accum) {
+				a.out_accum[(size_t)k[r] * 3 + 0] = acc.x;
+				a.out_accum[(size_t)k[r] * 3 + 1] = acc.y;
+				a.out_accum[(size_t)k[r] * 3 + 2] = acc.z;
+			}
+		}
+	}
+	wave_add_scans(a.scans, my_scans);
+}
+
+} // namespace sp

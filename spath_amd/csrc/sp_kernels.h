@@ -28,9 +28,14 @@ struct KArgs {
 
 // ---- repack: AoS geom::triangle -> scan records.  e1/e2 are the single float subtractions of
 // geom.h:200-201, hoisted out of the per-ray test (same bits).
-__global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, float4* __restrict__ scan, uint32_t n) {
+__global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, float4* __restrict__ scan, uint32_t n, uint32_t n_padded) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
+	if (i >= n_padded) return;
+	if (i >= n) {   // padding record: e1 = e2 = 0 -> a = 0 -> rejected at geom.h:204, can never be hit
+		const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		scan[(size_t)i * 3 + 0] = z; scan[(size_t)i * 3 + 1] = z; scan[(size_t)i * 3 + 2] = z;
+		return;
+	}
 	const float* t = tris + (size_t)i * 12;
 	const float v0x = t[0], v0y = t[1], v0z = t[2];
 	const float e1x = t[3] - v0x, e1y = t[4] - v0y, e1z = t[5] - v0z;
@@ -64,9 +69,59 @@ SP_DEV void scan_rpl_sload(const float4* __restrict__ scan, uint32_t n_tris, f3 
 	best_i = bi;
 }
 
+// ---- closest-hit scan, variant "rpl_lds": ray per lane; the workgroup streams the scan records
+// HBM/L2 -> registers -> LDS in coalesced 16-byte pieces (double-buffered tiles of kTile triangles),
+// and every lane reads the current triangle from LDS at a wave-uniform address (hardware broadcast),
+// so all VALU operands are VGPRs (SGPR operands run at ~63 % of the VGPR rate on gfx950, see
+// profiles/r01_first_contact_parity_and_valu_microbench.log).  One triangle fetched from L2/HBM is
+// shared by the 256 rays of the workgroup.  Must be called by every thread of the block.
+constexpr int kTile = 256;                      // triangles per LDS tile (12 KB), two tiles in flight
+constexpr int kTileQ = kTile * 3;               // float4 per tile
+static_assert(kTileQ % 256 == 0, "tile must split evenly over the 256 threads");
+
+SP_DEV void scan_rpl_lds(const float4* __restrict__ scan, uint32_t n_tris, f3 o, f3 dir, int src,
+                         float& best_d, int& best_i) {
+	__shared__ float4 sm[2 * kTileQ];
+	static_assert(kTileQ == 3 * 256, "three float4 per thread per tile");
+	const uint32_t tid = threadIdx.x;
+	const uint32_t ntiles = (n_tris + kTile - 1) / kTile;   // the scan buffer is zero-padded to whole tiles
+	float4 p0 = scan[tid], p1 = scan[256 + tid], p2 = scan[512 + tid];
+	__syncthreads();                            // readers of the previous scan are done with sm
+	sm[tid] = p0; sm[256 + tid] = p1; sm[512 + tid] = p2;
+	__syncthreads();
+	float bd = kMaxDist;
+	int bi = -1;
+	for (uint32_t t = 0; t < ntiles; ++t) {
+		const float4* cur = sm + (t & 1u) * kTileQ;
+		const bool more = (t + 1 < ntiles);
+		const float4* nsrc = scan + (size_t)(more ? t + 1 : t) * kTileQ;   // last tile: harmless re-read
+		p0 = nsrc[tid]; p1 = nsrc[256 + tid]; p2 = nsrc[512 + tid];
+		const uint32_t left = n_tris - t * kTile;
+		const uint32_t cnt = ((left < (uint32_t)kTile ? left : (uint32_t)kTile) + 3u) & ~3u;   // zero records never hit
+		const int base = (int)(t * kTile);
+#pragma unroll 4
+		for (uint32_t j = 0; j < cnt; ++j) {
+			const float4 q0 = cur[3 * j + 0], q1 = cur[3 * j + 1], q2 = cur[3 * j + 2];
+			const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+			const float d = ray_tri_strict(o, dir, v0, e1, e2);
+			const int idx = base + (int)j;
+			const bool take = (d > 0.0f) && (d < bd) && (idx != src);
+			bd = take ? d : bd;
+			bi = take ? idx : bi;
+		}
+		float4* nxt = sm + ((t + 1) & 1u) * kTileQ;   // not read before the barrier below + the next one
+		nxt[tid] = p0; nxt[256 + tid] = p1; nxt[512 + tid] = p2;
+		__syncthreads();
+	}
+	best_d = bd;
+	best_i = bi;
+}
+
+// VARIANT 1 = rpl_sload, 2 = rpl_lds.  Every variant must be called block-uniformly.
 template <int VARIANT>
 SP_DEV void closest_hit(const KArgs& a, f3 o, f3 dir, int src, float& best_d, int& best_i) {
-	scan_rpl_sload(a.scan, a.n_tris, o, dir, src, best_d, best_i);
+	if (VARIANT == 2) scan_rpl_lds(a.scan, a.n_tris, o, dir, src, best_d, best_i);
+	else scan_rpl_sload(a.scan, a.n_tris, o, dir, src, best_d, best_i);
 }
 
 SP_DEV void wave_add_scans(unsigned long long* ctr, uint32_t mine) {
@@ -124,7 +179,7 @@ __global__ void __launch_bounds__(256) k_pt(const KArgs a) {
 		bool alive = valid;
 #pragma unroll 1
 		for (int depth = 0; depth < 5; ++depth) {                // :33 depth >= 5 -> black
-			if (__ballot(alive) == 0ull) break;
+			if (!__syncthreads_or(alive ? 1 : 0)) break;   // block-uniform: the LDS scan has barriers
 			float bd; int bi;
 			if (depth == 0 && reuse) { bd = pd; bi = pi; }
 			else { closest_hit<VARIANT>(a, o, dir, src, bd, bi); my_scans += alive ? 1u : 0u; }

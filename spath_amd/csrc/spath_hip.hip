@@ -6,6 +6,7 @@
 // No exception crosses this boundary; every failure becomes a status + sphip_last_error().
 #include "spath_hip.h"
 #include "sp_kernels.h"
+#include "sp_filter_scan.h"
 
 #include <hip/hip_runtime.h>
 
@@ -29,7 +30,7 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, rays, rgba, accum, counter;
+	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter;
 	size_t n_tris = 0;
 	bool have_scene = false;
 	bool have_render = false, timed_upload = false, timed_download = false;
@@ -67,21 +68,28 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 	return SPHIP_OK;
 }
 
-constexpr int kNumVariants = 1;
-const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload" };
+constexpr int kNumVariants = 4;
+const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4" };
 
-int pick_variant(int flags, size_t /*n_tris*/) {
+int pick_variant(int flags, size_t n_tris) {
 	const int v = flags & SPHIP_KERNEL_MASK;
 	if (v >= 1 && v <= kNumVariants) return v;
-	return 1;
+	return n_tris >= 64 ? 3 : 1;      // tiny scenes: nothing to filter, the scalar path has no barriers
 }
 
 int repack(sphip_ctx* c, hipStream_t st) {
 	const uint32_t n = (uint32_t)c->n_tris;
-	int rc = ensure(c, c->scan, c->n_tris * 48);
+	const uint32_t n_pad = (n + sp::kTile - 1) / sp::kTile * sp::kTile;      // whole LDS tiles, zero records behind n
+	int rc = ensure(c, c->scan, (size_t)n_pad * 48);
 	if (rc) return rc;
-	hipLaunchKernelGGL(sp::k_repack, dim3((n + 255) / 256), dim3(256), 0, st,
-	                   (const float*)c->tris.p, (float4*)c->scan.p, n);
+	hipLaunchKernelGGL(sp::k_repack, dim3((n_pad + 255) / 256), dim3(256), 0, st,
+	                   (const float*)c->tris.p, (float4*)c->scan.p, n, n_pad);
+	HIP_TRY(c, hipGetLastError());
+	// filter records + scene bound for the two-stage scan (sp_filter_scan.h)
+	if ((rc = ensure(c, c->filt, (size_t)n_pad * 48)) || (rc = ensure(c, c->bounds, 256))) return rc;
+	HIP_TRY(c, hipMemsetAsync(c->bounds.p, 0, 256, st));
+	hipLaunchKernelGGL(sp::k_repack_filter, dim3((n_pad + 255) / 256), dim3(256), 0, st,
+	                   (const float*)c->tris.p, (float4*)c->filt.p, (unsigned int*)c->bounds.p, n, n_pad);
 	HIP_TRY(c, hipGetLastError());
 	c->have_scene = true;
 	return SPHIP_OK;
@@ -122,9 +130,21 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	const int variant = pick_variant(flags, c->n_tris);
 	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(unsigned long long), st));
 	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
+	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
+	const float4* filt = (const float4*)c->filt.p;
+	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-	if (mode == SPHIP_MODE_FLAT) hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
-	else                         hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
+	if (mode == SPHIP_MODE_FLAT) {
+		if (variant == 4)      hipLaunchKernelGGL(sp::k_flat_filter<4>, grid4, block, 0, st, a, filt, bnd);
+		else if (variant == 3) hipLaunchKernelGGL(sp::k_flat_filter<2>, grid2, block, 0, st, a, filt, bnd);
+		else if (variant == 2) hipLaunchKernelGGL(sp::k_flat<2>, grid, block, 0, st, a);
+		else                   hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
+	} else {
+		if (variant == 4)      hipLaunchKernelGGL(sp::k_pt_filter<4>, grid4, block, 0, st, a, filt, bnd);
+		else if (variant == 3) hipLaunchKernelGGL(sp::k_pt_filter<2>, grid2, block, 0, st, a, filt, bnd);
+		else if (variant == 2) hipLaunchKernelGGL(sp::k_pt<2>, grid, block, 0, st, a);
+		else                   hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
+	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipEventRecord(c->ev_k1, st));
 	c->have_render = true;
@@ -184,7 +204,7 @@ void sphip_destroy(sphip_t* c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[7] = { &c->tris, &c->mats, &c->scan, &c->rays, &c->rgba, &c->accum, &c->counter };
+	DevBuf* bufs[9] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->rays, &c->rgba, &c->accum, &c->counter };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
