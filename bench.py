@@ -117,7 +117,6 @@ def main():
     torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    scans_total = 0
     image = None
 
     def step(i_timed=None):
@@ -141,7 +140,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        scans_total += 0
     fence()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()                       # figures of the last launch on this rank

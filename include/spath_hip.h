@@ -103,6 +103,13 @@ int sphip_render_device(sphip_t* ctx, const void* d_rays /* n_rays*6 f32: the sh
                         void* d_out_rgba /* n_rays*4 u8 */, void* d_out_accum /* n_rays*3 f32 or NULL */,
                         void* stream);
 
+/* The closest-hit scan on its own (the loop of src/cpu_renderer.cpp:36-49 for each ray): for ray k writes the
+ * index of the nearest accepted triangle (or -1) and its distance d (MAX_VALUE_DIST = 1e12f on a miss).
+ * d_src_idx (may be NULL) gives each ray's idx_source, the triangle to skip (:40-41); NULL means -1 for all.
+ * Used by the parity tests to compare scan kernels hit for hit; asynchronous like sphip_render_device. */
+int sphip_closest_hit_device(sphip_t* ctx, const void* d_rays, size_t n_rays, const void* d_src_idx /* n_rays i32 or NULL */,
+                             int flags, void* d_out_idx /* n_rays i32 */, void* d_out_dist /* n_rays f32 */, void* stream);
+
 /* Blocks until the last render on this context has finished, then reports its figures. */
 int sphip_get_stats(sphip_t* ctx, sphip_stats* out);
 

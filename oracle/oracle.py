@@ -57,6 +57,7 @@ def lib():
         L.spo_ray_intersect.argtypes = [vp, vp, vp]
         L.spo_closest_hit.restype = C.c_int
         L.spo_closest_hit.argtypes = [vp, vp, C.c_size_t, C.c_int, fp, vp]
+        L.spo_closest_hit_batch.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
         L.spo_flat_normal.argtypes = [vp]
         L.spo_consts.argtypes = [fp, C.POINTER(C.c_double)]
         L.spo_camera_init.argtypes = [vp, C.c_size_t, C.c_size_t]
@@ -109,6 +110,17 @@ def render_counter(rays, tris, mats, n_samples, seed, pix0=0, npix=None, workers
     lib().spo_render_counter(_p(rays), pix0, npix, _p(tris), _p(mats), tris.shape[0], n_samples,
                              C.c_uint64(seed), workers, _p(out), _p(acc), C.byref(scans))
     return out, acc, int(scans.value)
+
+
+def closest_hits(rays, tris, src_idx=None):
+    """cpu_renderer.cpp:36-49 for a batch of rays: (idx [n] i32, d [n] f32)."""
+    rays = np.ascontiguousarray(rays, dtype=F).reshape(-1, 6)
+    tris = np.ascontiguousarray(tris, dtype=F).reshape(-1, 12)
+    idx = np.zeros(rays.shape[0], dtype=np.int32)
+    d = np.zeros(rays.shape[0], dtype=F)
+    src = None if src_idx is None else np.ascontiguousarray(src_idx, dtype=np.int32)
+    lib().spo_closest_hit_batch(_p(rays), rays.shape[0], _p(tris), tris.shape[0], _p(src) if src is not None else None, _p(idx), _p(d))
+    return idx, d
 
 
 def viewport(w, h, moves=()):

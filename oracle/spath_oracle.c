@@ -248,6 +248,13 @@ int spo_closest_hit(const spo_ray* r, const spo_tri* tris, size_t n_tris, int id
 	return idx;
 }
 
+/* the same scan for a batch of rays (test helper) */
+void spo_closest_hit_batch(const spo_ray* rays, size_t n_rays, const spo_tri* tris, size_t n_tris, const int* src_idx,
+                           int* out_idx, float* out_d) {
+	for (size_t k = 0; k < n_rays; ++k)
+		out_idx[k] = spo_closest_hit(&rays[k], tris, n_tris, src_idx ? src_idx[k] : -1, &out_d[k], 0);
+}
+
 typedef struct {
 	const spo_tri* tris; const spo_mat* mats; size_t n_tris;
 	uint64_t scans;

@@ -20,7 +20,7 @@ FLAG_PRIMARY_REUSE = 0x100
 SYMBOLS = (
     "sphip_create", "sphip_destroy", "sphip_last_error", "sphip_description", "sphip_abi_version",
     "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
-    "sphip_render_device", "sphip_get_stats",
+    "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats",
 )
 
 
@@ -73,6 +73,8 @@ def load():
     L.sphip_set_scene_device.argtypes = [vp, vp, vp, sz, vp]
     L.sphip_render_device.restype = C.c_int
     L.sphip_render_device.argtypes = [vp, vp, sz, C.POINTER(Shard), sz, sz, C.c_uint64, C.c_int, C.c_int, vp, vp, vp]
+    L.sphip_closest_hit_device.restype = C.c_int
+    L.sphip_closest_hit_device.argtypes = [vp, vp, sz, vp, C.c_int, vp, vp, vp]
     L.sphip_get_stats.restype = C.c_int
     L.sphip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     _lib = L
@@ -154,6 +156,11 @@ class Context:
             sh = C.byref(Shard(*[int(v) for v in shard]))
         self._check(self._L.sphip_render_device(self._h, d_rays, n_rays, sh, image_width, n_samples, seed, mode, flags,
                                                 d_out_rgba, d_out_accum or None, stream or None), "sphip_render_device")
+
+    def closest_hit_device(self, d_rays: int, n_rays: int, d_out_idx: int, d_out_dist: int, *, d_src_idx: int = 0,
+                           flags=0, stream: int = 0):
+        self._check(self._L.sphip_closest_hit_device(self._h, d_rays, n_rays, d_src_idx or None, flags,
+                                                     d_out_idx, d_out_dist, stream or None), "sphip_closest_hit_device")
 
     def stats(self) -> dict:
         s = Stats()

@@ -92,6 +92,21 @@ SP_DEV void exact_range(const float4* __restrict__ scan, uint32_t lo, uint32_t h
 	}
 }
 
+// stage 1 for one (triangle record, ray): true = survivor
+SP_DEV bool slab_survives(const float4 q0, const float4 q1, const float m1z, const f3 P, const f3 dir, const float dq) {
+	float A = q0.x * P.x;
+	A = __builtin_fmaf(q0.y, P.y, A);
+	A = __builtin_fmaf(q0.z, P.z, A);
+	float g0 = __builtin_fmaf(-dir.x, q0.w, A);
+	g0 = __builtin_fmaf(-dir.y, q1.x, g0);
+	g0 = __builtin_fmaf(-dir.z, q1.y, g0);
+	float g1 = __builtin_fmaf(-dir.x, q1.z, A);
+	g1 = __builtin_fmaf(-dir.y, q1.w, g1);
+	g1 = __builtin_fmaf(-dir.z, m1z, g1);
+	const float m = __builtin_amdgcn_fmed3f(g0, g1, 0.0f);
+	return !(fabsf(m) > dq);          // NaN-safe: anything unordered survives
+}
+
 // Closest hit for the R rays of every lane.  Block-uniform call (barriers inside).
 template <int R>
 SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
@@ -127,33 +142,40 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		p0 = nsrc[tid]; p1 = nsrc[256 + tid]; p2 = nsrc[512 + tid];
 		const uint32_t left = n_tris - t * kTile;
 		const uint32_t cnt = left < (uint32_t)kTile ? left : (uint32_t)kTile;
+		const uint32_t cnt2 = (cnt + 1u) & ~1u;   // pairs; an odd tail reads one padding record (w = M = 0: survives,
+		                                          // and is then rejected by the exact stage: zero exact record)
 		const uint32_t base = t * kTile;
-		uint32_t qn = 0;           // entries queued by this lane in this tile
-		bool ovf = false;
-#pragma unroll 2
-		for (uint32_t j = 0; j < cnt; ++j) {
-			const float4 q0 = cur[3 * j + 0], q1 = cur[3 * j + 1], q2 = cur[3 * j + 2];
+		uint32_t qn = 0;                          // survivors of this lane in this tile (may exceed kQCap: overflow)
+		for (uint32_t j = 0; j < cnt2; j += 2) {
+			const float4 a0 = cur[3 * j + 0], a1 = cur[3 * j + 1];
+			const float a2 = cur[3 * j + 2].x;
+			const float4 b0 = cur[3 * j + 3], b1 = cur[3 * j + 4];
+			const float b2 = cur[3 * j + 5].x;
+			bool sa[R], sb[R];
+			bool any = false;
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
-				float A = q0.x * P[r].x;
-				A = __builtin_fmaf(q0.y, P[r].y, A);
-				A = __builtin_fmaf(q0.z, P[r].z, A);
-				float g0 = __builtin_fmaf(-s.dir[r].x, q0.w, A);
-				g0 = __builtin_fmaf(-s.dir[r].y, q1.x, g0);
-				g0 = __builtin_fmaf(-s.dir[r].z, q1.y, g0);
-				float g1 = __builtin_fmaf(-s.dir[r].x, q1.z, A);
-				g1 = __builtin_fmaf(-s.dir[r].y, q1.w, g1);
-				g1 = __builtin_fmaf(-s.dir[r].z, q2.x, g1);
-				const float m = __builtin_amdgcn_fmed3f(g0, g1, 0.0f);
-				if (!(fabsf(m) > Dq[r])) {                 // survivor (rare): queue it
-					if (qn < (uint32_t)kQCap) qs[qn * 256 + tid] = (unsigned short)((r << 8) | j);
-					else ovf = true;
-					qn += (qn < (uint32_t)kQCap) ? 1u : 0u;
+				sa[r] = slab_survives(a0, a1, a2, P[r], s.dir[r], Dq[r]);
+				sb[r] = slab_survives(b0, b1, b2, P[r], s.dir[r], Dq[r]);
+				any |= sa[r] | sb[r];
+			}
+			if (any) {                            // rare: queue the survivors, triangle-major so the order stays ascending
+#pragma unroll
+				for (int r = 0; r < R; ++r) if (sa[r]) {
+					const uint32_t e = qn < (uint32_t)kQCap ? qn : (uint32_t)kQCap - 1u;
+					qs[e * 256 + tid] = (unsigned short)((r << 8) | j);
+					++qn;
+				}
+#pragma unroll
+				for (int r = 0; r < R; ++r) if (sb[r]) {
+					const uint32_t e = qn < (uint32_t)kQCap ? qn : (uint32_t)kQCap - 1u;
+					qs[e * 256 + tid] = (unsigned short)((r << 8) | (j + 1));
+					++qn;
 				}
 			}
 		}
 		// ---- stage 2: exact tests of this tile's survivors, in queue (= index) order
-		if (__builtin_expect(__any(ovf), 0)) {
+		if (__builtin_expect(__any(qn > (uint32_t)kQCap), 0)) {
 			// some lane overflowed its queue: the whole wave re-scans the tile exactly (rare: scenes made of
 			// triangles so large that most rays cross their slabs)
 			exact_range<R>(a.scan, base, base + cnt, s, bd, bi);
@@ -182,6 +204,30 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		nxt[tid] = p0; nxt[256 + tid] = p1; nxt[512 + tid] = p2;
 		__syncthreads();
 	}
+}
+
+// ---- the closest-hit scan alone with the filter scan; R rays per lane
+template <int R>
+__global__ void __launch_bounds__(256) k_hit_filter(const KArgs a, const float4* __restrict__ filt, const unsigned int* __restrict__ bounds,
+                                                    const int* __restrict__ src_idx, int* __restrict__ out_idx, float* __restrict__ out_d) {
+	const float rv = __uint_as_float(bounds[0]);
+	RaySlots<R> s;
+	uint32_t k[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		k[r] = blockIdx.x * (256u * R) + r * 256u + threadIdx.x;
+		const bool valid = k[r] < a.n_rays;
+		const uint32_t kk = valid ? k[r] : a.n_rays - 1;
+		const float* p = a.rays + (size_t)kk * 6;
+		s.o[r] = mk3(p[0], p[1], p[2]); s.dir[r] = mk3(p[3], p[4], p[5]);
+		s.src[r] = src_idx ? src_idx[kk] : -1; s.act[r] = valid;
+	}
+	float bd[R]; int bi[R];
+	scan_filter<R>(a, filt, rv, s, bd, bi);
+	uint32_t nsc = 0;
+#pragma unroll
+	for (int r = 0; r < R; ++r) if (k[r] < a.n_rays) { out_idx[k[r]] = bi[r]; out_d[k[r]] = bd[r]; nsc++; }
+	wave_add_scans(a.scans, nsc);
 }
 
 // ---- renderer::render_flat with the filter scan; R pixels per lane
@@ -216,21 +262,25 @@ __global__ void __launch_bounds__(256) k_flat_filter(const KArgs a, const float4
 	wave_add_scans(a.scans, nsc);
 }
 
-// ---- renderer::render with the filter scan; R pixels per lane, all R paths advance in lock-step
+// ---- renderer::render with the filter scan; R pixels per lane, all R paths advance in lock-step.
+// Per-path history (hit index and cos(theta) per depth) and the per-pixel accumulator are parked in a
+// global work buffer between scans instead of being held in VGPRs through the scan loop: 52 B per pixel,
+// touched once per bounce, against ~10^5 VALU instructions per bounce.
+//   work layout: hist[depth][k] = {idx, cos bits} (8 B), then acc[c][k] (3 floats), k < n_work
 template <int R>
-__global__ void __launch_bounds__(256) k_pt_filter(const KArgs a, const float4* __restrict__ filt, const unsigned int* __restrict__ bounds) {
+__global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, const float4* __restrict__ filt, const unsigned int* __restrict__ bounds,
+                                                   int2* __restrict__ hist, float* __restrict__ acc, uint32_t n_work) {
 	const float rv = __uint_as_float(bounds[0]);
 	const uint32_t tid = threadIdx.x;
-	uint32_t k[R], pixel[R];
-	bool valid[R];
-	const float* prim[R];
+	const uint32_t k0 = blockIdx.x * (256u * R) + tid;       // slot r handles ray k0 + r*256
+	uint32_t pixel[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		k[r] = blockIdx.x * (256u * R) + r * 256u + tid;
-		valid[r] = k[r] < a.n_rays;
-		const uint32_t kk = valid[r] ? k[r] : a.n_rays - 1;
-		prim[r] = a.rays + (size_t)kk * 6;
+		const uint32_t k = k0 + r * 256u;
+		const uint32_t kk = k < a.n_rays ? k : a.n_rays - 1;
 		pixel[r] = (uint32_t)shard_pixel(a, kk);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) acc[(size_t)c * n_work + k] = 0.0f;
 	}
 	const bool reuse = (a.flags & 0x100u) != 0;
 	uint32_t my_scans = 0;
@@ -239,27 +289,27 @@ __global__ void __launch_bounds__(256) k_pt_filter(const KArgs a, const float4* 
 		RaySlots<R> s;
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
-			s.o[r] = mk3(prim[r][0], prim[r][1], prim[r][2]); s.dir[r] = mk3(prim[r][3], prim[r][4], prim[r][5]);
-			s.src[r] = -1; s.act[r] = valid[r];
-			my_scans += valid[r] ? 1u : 0u;
+			const uint32_t k = k0 + r * 256u;
+			const bool valid = k < a.n_rays;
+			const float* pr = a.rays + (size_t)(valid ? k : a.n_rays - 1) * 6;
+			s.o[r] = mk3(pr[0], pr[1], pr[2]); s.dir[r] = mk3(pr[3], pr[4], pr[5]);
+			s.src[r] = -1; s.act[r] = valid;
+			my_scans += valid ? 1u : 0u;
 		}
 		scan_filter<R>(a, filt, rv, s, pd, pi);
 	}
 
-	f3 accum[R];
-#pragma unroll
-	for (int r = 0; r < R; ++r) accum[r] = mk3(0.0f, 0.0f, 0.0f);
-
 	for (uint32_t smp = 0; smp < a.n_samples; ++smp) {
 		RaySlots<R> s;
-		int hidx[R][5];
-		float hcos[R][5];
+		int nh[R];                       // surface hits of this path so far
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
-			s.o[r] = mk3(prim[r][0], prim[r][1], prim[r][2]); s.dir[r] = mk3(prim[r][3], prim[r][4], prim[r][5]);
-			s.src[r] = -1; s.act[r] = valid[r];
-#pragma unroll
-			for (int d = 0; d < 5; ++d) { hidx[r][d] = -1; hcos[r][d] = 0.0f; }
+			const uint32_t k = k0 + r * 256u;
+			const bool valid = k < a.n_rays;
+			const float* pr = a.rays + (size_t)(valid ? k : a.n_rays - 1) * 6;
+			s.o[r] = mk3(pr[0], pr[1], pr[2]); s.dir[r] = mk3(pr[3], pr[4], pr[5]);
+			s.src[r] = -1; s.act[r] = valid;
+			nh[r] = 0;
 		}
 #pragma unroll 1
 		for (int depth = 0; depth < 5; ++depth) {
@@ -290,36 +340,40 @@ __global__ void __launch_bounds__(256) k_pt_filter(const KArgs a, const float4* 
 					s.o[r] = add3(s.o[r], scale3(s.dir[r], bd[r]));
 					s.dir[r] = nd;
 					s.src[r] = bi[r];
-#pragma unroll
-					for (int d = 0; d < 5; ++d) if (depth == d) { hidx[r][d] = bi[r]; hcos[r][d] = ct; }
+					hist[(size_t)depth * n_work + k0 + r * 256u] = make_int2(bi[r], (int)__float_as_uint(ct));
+					nh[r] = depth + 1;
 				}
 				s.act[r] = hit;
 			}
 		}
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
+			const uint32_t k = k0 + r * 256u;
 			f3 rec = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-			for (int d = 4; d >= 0; --d) {
-				if (hidx[r][d] >= 0) {
-					const float* m = a.mats + (size_t)hidx[r][d] * 6;
-					const f3 brdf = scale3(mk3(m[0], m[1], m[2]), kInvPi);
-					const f3 e = mk3(m[3], m[4], m[5]);
-					rec = add3(e, scale3(scale3(mul3(brdf, rec), hcos[r][d]), kInvP));
-				}
+			for (int d = nh[r] - 1; d >= 0; --d) {
+				const int2 hc = hist[(size_t)d * n_work + k];
+				const float* m = a.mats + (size_t)hc.x * 6;
+				const f3 brdf = scale3(mk3(m[0], m[1], m[2]), kInvPi);
+				const f3 e = mk3(m[3], m[4], m[5]);
+				rec = add3(e, scale3(scale3(mul3(brdf, rec), __uint_as_float((uint32_t)hc.y)), kInvP));
 			}
-			accum[r] = add3(accum[r], rec);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				float* p = acc + (size_t)c * n_work + k;
+				*p = *p + (c == 0 ? rec.x : c == 1 ? rec.y : rec.z);          // cpu_renderer.cpp:75, same order
+			}
 		}
 	}
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		const f3 acc = scale3(accum[r], a.inv_n);
-		if (valid[r]) {
-			a.out_rgba[k[r]] = vec3_rgba(mk3(clamp01(acc.x), clamp01(acc.y), clamp01(acc.z)));
+		const uint32_t k = k0 + r * 256u;
+		if (k < a.n_rays) {
+			const f3 av = scale3(mk3(acc[k], acc[(size_t)n_work + k], acc[(size_t)2 * n_work + k]), a.inv_n);
+			a.out_rgba[k] = vec3_rgba(mk3(clamp01(av.x), clamp01(av.y), clamp01(av.z)));
 			if (a.out_accum) {
-				a.out_accum[(size_t)k[r] * 3 + 0] = acc.x;
-				a.out_accum[(size_t)k[r] * 3 + 1] = acc.y;
-				a.out_accum[(size_t)k[r] * 3 + 2] = acc.z;
+				a.out_accum[(size_t)k * 3 + 0] = av.x;
+				a.out_accum[(size_t)k * 3 + 1] = av.y;
+				a.out_accum[(size_t)k * 3 + 2] = av.z;
 			}
 		}
 	}

@@ -151,6 +151,19 @@ __global__ void __launch_bounds__(256) k_flat(const KArgs a) {
 	wave_add_scans(a.scans, valid ? 1u : 0u);
 }
 
+// ---- the closest-hit scan alone (cpu_renderer.cpp:36-49), one ray per lane
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_hit(const KArgs a, const int* __restrict__ src_idx, int* __restrict__ out_idx, float* __restrict__ out_d) {
+	const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+	const bool valid = k < a.n_rays;
+	const uint32_t kk = valid ? k : a.n_rays - 1;
+	const float* r = a.rays + (size_t)kk * 6;
+	float bd; int bi;
+	closest_hit<VARIANT>(a, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), src_idx ? src_idx[kk] : -1, bd, bi);
+	if (valid) { out_idx[k] = bi; out_d[k] = bd; }
+	wave_add_scans(a.scans, valid ? 1u : 0u);
+}
+
 // ---- renderer::render (cpu_renderer.cpp:29-79): n_samples x (<=5 surface hits).
 // The recursion of render_step is run forward (store idx and cos(theta) per depth) and unwound
 // backward in the reference's own evaluation order  E + (((BRDF*rec)*cos)*(1/p))  (:67) -- the

@@ -30,7 +30,7 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter;
+	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter, work;
 	size_t n_tris = 0;
 	bool have_scene = false;
 	bool have_render = false, timed_upload = false, timed_download = false;
@@ -95,12 +95,16 @@ int repack(sphip_ctx* c, hipStream_t st) {
 	return SPHIP_OK;
 }
 
+constexpr int kModeHits = 2;   // internal: sphip_closest_hit_device
+
 int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_shard* shard, size_t /*image_width*/,
-                  size_t n_samples, uint64_t seed, int mode, int flags, void* d_rgba, void* d_accum, hipStream_t st) {
+                  size_t n_samples, uint64_t seed, int mode, int flags, void* d_rgba, void* d_accum, hipStream_t st,
+                  const int* d_src = nullptr) {
 	if (!c->have_scene) return fail(c, SPHIP_E_STATE, "render called before a scene was set");
 	if (!d_rays || !d_rgba) return fail(c, SPHIP_E_INVALID, "null ray or output pointer");
 	if (n_rays == 0 || n_rays > 0xffffffffull) return fail(c, SPHIP_E_INVALID, "n_rays %zu out of range", n_rays);
-	if (mode != SPHIP_MODE_FLAT && mode != SPHIP_MODE_PT) return fail(c, SPHIP_E_INVALID, "unknown mode %d", mode);
+	if (mode != SPHIP_MODE_FLAT && mode != SPHIP_MODE_PT && mode != kModeHits) return fail(c, SPHIP_E_INVALID, "unknown mode %d", mode);
+	if (mode == kModeHits && !d_accum) return fail(c, SPHIP_E_INVALID, "null distance output");
 	if (mode == SPHIP_MODE_PT && (n_samples == 0 || n_samples > 0x7fffffffull))
 		return fail(c, SPHIP_E_INVALID, "n_samples must be in [1, 2^31) (the reference divides by it, cpu_renderer.cpp:77)");
 	int rc = ensure(c, c->counter, sizeof(unsigned long long));
@@ -131,17 +135,31 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(unsigned long long), st));
 	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
 	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
+	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray
+	const uint32_t n_work = (uint32_t)((n_rays + 1023) / 1024 * 1024);
+	int2* hist = nullptr; float* acc = nullptr;
+	if (mode == SPHIP_MODE_PT && variant >= 3) {
+		if ((rc = ensure(c, c->work, (size_t)n_work * 52))) return rc;
+		hist = (int2*)c->work.p;
+		acc = (float*)((char*)c->work.p + (size_t)n_work * 40);
+	}
 	const float4* filt = (const float4*)c->filt.p;
 	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-	if (mode == SPHIP_MODE_FLAT) {
+	if (mode == kModeHits) {
+		int* oi = (int*)d_rgba; float* od = (float*)d_accum;
+		if (variant == 4)      hipLaunchKernelGGL(sp::k_hit_filter<4>, grid4, block, 0, st, a, filt, bnd, d_src, oi, od);
+		else if (variant == 3) hipLaunchKernelGGL(sp::k_hit_filter<2>, grid2, block, 0, st, a, filt, bnd, d_src, oi, od);
+		else if (variant == 2) hipLaunchKernelGGL(sp::k_hit<2>, grid, block, 0, st, a, d_src, oi, od);
+		else                   hipLaunchKernelGGL(sp::k_hit<1>, grid, block, 0, st, a, d_src, oi, od);
+	} else if (mode == SPHIP_MODE_FLAT) {
 		if (variant == 4)      hipLaunchKernelGGL(sp::k_flat_filter<4>, grid4, block, 0, st, a, filt, bnd);
 		else if (variant == 3) hipLaunchKernelGGL(sp::k_flat_filter<2>, grid2, block, 0, st, a, filt, bnd);
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_flat<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
 	} else {
-		if (variant == 4)      hipLaunchKernelGGL(sp::k_pt_filter<4>, grid4, block, 0, st, a, filt, bnd);
-		else if (variant == 3) hipLaunchKernelGGL(sp::k_pt_filter<2>, grid2, block, 0, st, a, filt, bnd);
+		if (variant == 4)      hipLaunchKernelGGL(sp::k_pt_filter<4>, grid4, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		else if (variant == 3) hipLaunchKernelGGL(sp::k_pt_filter<2>, grid2, block, 0, st, a, filt, bnd, hist, acc, n_work);
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_pt<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
 	}
@@ -204,7 +222,7 @@ void sphip_destroy(sphip_t* c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[9] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->rays, &c->rgba, &c->accum, &c->counter };
+	DevBuf* bufs[10] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -249,6 +267,14 @@ int sphip_render_device(sphip_t* c, const void* d_rays, size_t n_rays, const sph
 	HIP_TRY(c, hipSetDevice(c->device));
 	c->timed_upload = c->timed_download = false;
 	return launch_render(c, d_rays, n_rays, shard, image_width, n_samples, seed, mode, flags, d_out_rgba, d_out_accum, (hipStream_t)stream);
+}
+
+int sphip_closest_hit_device(sphip_t* c, const void* d_rays, size_t n_rays, const void* d_src_idx, int flags,
+                             void* d_out_idx, void* d_out_dist, void* stream) {
+	if (!c) return SPHIP_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	c->timed_upload = c->timed_download = false;
+	return launch_render(c, d_rays, n_rays, nullptr, 0, 1, 0, kModeHits, flags, d_out_idx, d_out_dist, (hipStream_t)stream, (const int*)d_src_idx);
 }
 
 int sphip_render(sphip_t* c, const float* rays, size_t w, size_t h, size_t n_samples, uint64_t seed, int mode, int flags,

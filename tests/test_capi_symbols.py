@@ -1,0 +1,68 @@
+"""The C-ABI library loads and exports every entry point include/spath_hip.h declares (no compute, no GPU)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "spath_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sphip_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from spath_amd import capi
+    assert declared_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    from spath_amd import capi
+    assert os.path.exists(capi.LIB_PATH), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    lib = C.CDLL(capi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    L = capi.load()
+    assert L.sphip_abi_version() == 1
+    assert L.sphip_kernel_name(0) == b"auto" and L.sphip_kernel_name(99) is None
+    assert set(capi.kernel_variants()) >= {"auto", "rpl_sload", "rpl_lds", "rpl_filter2"}
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    """Without a GPU sphip_create must fail with a message; nothing falls back to the CPU."""
+    import torch
+    from spath_amd import capi
+    if torch.cuda.is_available():
+        return
+    try:
+        capi.Context(0)
+    except capi.SpathHipError as e:
+        assert "sphip_create" in str(e)
+    else:
+        raise AssertionError("sphip_create succeeded without a GPU")
+
+
+def test_product_package_never_imports_the_oracle():
+    import ast
+    pkg = os.path.join(ROOT, "spath_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dp, f)).read())
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or ""]
+                    assert not any(n.split(".")[0] == "oracle" for n in names), (f, names)
+    import re
+    for sub in ("csrc", "host"):
+        for dp, _, fs in os.walk(os.path.join(pkg, sub)):
+            for f in fs:
+                if f.endswith((".so", ".o")) or "/build" in dp:
+                    continue
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', src), f
+                assert "liboracle" not in src and "spo_" not in src, f

@@ -1,0 +1,317 @@
+"""Legs B and C of the parity chain, on a real MI355X, through the C ABI (spath_amd/capi.py -> libspath_hip.so).
+
+Leg B (bit-exact): HIP kernels vs the CPU oracle with the same counter RNG and the same strict float
+arithmetic.  STATED TOLERANCE: per-pixel L-infinity = 0 on the float accumulators (accum/n before
+clamping) and on the RGBA8 image; closest-hit index and distance identical; scan counts identical.
+The flat pass (RNG-free) is additionally compared with images produced by the reference itself.
+
+Leg C (statistical): HIP path tracing vs the reference's own RNG stream (cpu_renderer, T = 8) at
+1024 spp: image-mean and 8x8 block-mean tolerances calibrated on reference-vs-reference noise
+(0.035 % and 3.25/255 between two reference streams).
+"""
+import numpy as np
+import pytest
+import torch
+
+from spath_amd import capi, scene, view
+from spath_amd.dist import RowTilePlan, ShardedRenderer
+
+pytestmark = pytest.mark.gpu
+
+ACCUM_LINF_TOLERANCE = 0.0          # float accumulators: exact
+VARIANTS = [1, 2, 3, 4]             # rpl_sload, rpl_lds, rpl_filter2, rpl_filter4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def render_pt(hip, rays, w, h, spp, seed, flags=0):
+    img, acc = hip.render(rays, w, h, spp, seed=seed, flags=flags, want_accum=True)
+    return img, acc, hip.stats()
+
+
+SCENES = {
+    "default": lambda: scene.default_scene(),
+    "closed1k": lambda: scene.closed_room(1000),
+    "open300": lambda: scene.open_clutter(300),
+    "bigtris": lambda: scene.closed_room(600, clutter_scale=10.0),     # most rays cross most slabs: queue overflow path
+    "odd257": lambda: scene.closed_room(257),                          # one triangle past a tile boundary
+}
+
+
+@pytest.mark.parametrize("name,w,h,spp,seed", [
+    ("default", 320, 240, 4, 1), ("default", 67, 41, 3, 99), ("closed1k", 96, 64, 2, 1), ("open300", 128, 96, 3, 0xDEADBEEF12345),
+    ("bigtris", 48, 36, 2, 5), ("odd257", 50, 30, 2, 2), ("default", 1, 1, 7, 3), ("default", 513, 2, 1, 8),
+])
+def test_leg_b_flat_and_path_trace_bit_exact(hip, O, name, w, h, spp, seed):
+    t, m = SCENES[name]()
+    rays = view.Camera(w, h).get_viewport()
+    hip.set_scene(t, m)
+    want_flat = O.render_flat(rays, w, h, t, m)
+    want_img, want_acc, want_scans = O.render_counter(rays, t, m, spp, seed)
+    for v in VARIANTS:
+        flat = hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=v)
+        assert np.array_equal(flat, want_flat), (name, v, "flat")
+        img, acc, st = render_pt(hip, rays, w, h, spp, seed, flags=v)
+        assert st["kernel_variant"] == v
+        assert np.abs(acc - want_acc).max() <= ACCUM_LINF_TOLERANCE and np.array_equal(acc, want_acc), (name, v, "accum")
+        assert np.array_equal(img, want_img), (name, v, "rgba")
+        assert st["scans_executed"] == want_scans, (name, v)
+
+
+def test_flat_equals_reference_fixtures(hip, O, golden, ref_images, scenes):
+    """RNG-free pass against what the REFERENCE produced (committed fixtures), not only against the oracle."""
+    for e in golden["renders"]:
+        if e["mode"] != "flat":
+            continue
+        t, m = scenes[e["scene"]]
+        moves = [(k, tuple(v) if isinstance(v, list) else v) for k, v in e["moves"]]
+        rays = O.viewport(e["w"], e["h"], moves)
+        hip.set_scene(t, m)
+        for v in VARIANTS:
+            img = hip.render(rays, e["w"], e["h"], 1, mode=capi.MODE_FLAT, flags=v)
+            assert O.fnv1a64(img.tobytes()) == e["fnv1a64"], (e["scene"], v)
+    hip.set_scene(*scenes["default"])
+    rays = O.viewport(64, 48, [("mov", (0.3, 0.1, -0.5)), ("rot", (0.1, -0.25, 0.0)), ("focal", 0.5)])
+    assert np.array_equal(hip.render(rays, 64, 48, 1, mode=capi.MODE_FLAT), ref_images["default_flat_64x48_s1_T8_moved"])
+
+
+def test_flat_equals_live_reference_binary(hip, O):
+    """Where the compiled reference travelled to the box: its render_flat on a synthetic scene, exact."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref/spath_ref not present")
+    t, m = scene.closed_room(2000)
+    w, h = 160, 90
+    want = O.ref_run("flat", w, h, 1, t, m)
+    hip.set_scene(t, m)
+    for v in VARIANTS:
+        assert np.array_equal(hip.render(O.viewport(w, h), w, h, 1, mode=capi.MODE_FLAT, flags=v), want), v
+
+
+def _adversarial_rays(t, rng, n_extra=4000):
+    """Rays aimed exactly at vertices, edge midpoints and centroids of triangles (the filter's worst cases),
+    grazing rays in triangle planes, and random rays."""
+    v = t[:, :9].reshape(-1, 3, 3).astype(np.float64)
+    sel = rng.integers(0, v.shape[0], n_extra)
+    tri = v[sel]
+    kind = rng.integers(0, 6, n_extra)
+    w = np.zeros((n_extra, 3))
+    w[kind == 0] = [1, 0, 0]; w[kind == 1] = [0, 1, 0]; w[kind == 2] = [0, 0, 1]       # vertices
+    w[kind == 3] = [0.5, 0.5, 0]; w[kind == 4] = [0, 0.5, 0.5]; w[kind == 5] = [1 / 3, 1 / 3, 1 / 3]
+    target = (tri * w[:, :, None]).sum(axis=1)
+    origin = rng.uniform(-3.5, 3.5, (n_extra, 3)) * [1, 0.3, 1] + [0, 0.5, 0]
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aimed = np.concatenate([origin, d], axis=1)
+    # grazing: origin in the plane of a triangle, direction along an edge
+    e = tri[:, 1] - tri[:, 0]
+    graze = np.concatenate([tri[:, 2] - 2.0 * e, e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-30)], axis=1)
+    rnd = np.concatenate([rng.uniform(-3, 3, (n_extra, 3)), rng.normal(size=(n_extra, 3))], axis=1)
+    rnd[:, 3:] /= np.linalg.norm(rnd[:, 3:], axis=1, keepdims=True)
+    unnorm = rnd.copy(); unnorm[:, 3:] *= rng.uniform(1e-3, 1e3, (n_extra, 1))        # caller rays need not be unit length
+    return np.concatenate([aimed, graze, rnd, unnorm]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["closed1k", "open300", "bigtris", "default"])
+def test_closest_hit_scan_hit_for_hit(hip, O, name):
+    """cpu_renderer.cpp:36-49 alone: every scan kernel returns the oracle's (index, distance) for adversarial
+    rays, with and without an idx_source to skip -- this is the check that the conservative filter never
+    rejects a pair the reference accepts."""
+    t, m = SCENES[name]()
+    rng = np.random.default_rng(11)
+    rays = _adversarial_rays(t, rng)
+    n = rays.shape[0]
+    src = rng.integers(-1, t.shape[0], n).astype(np.int32)
+    hip.set_scene(t, m)
+    d_rays, d_src = dev(rays), dev(src)
+    d_idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_d = torch.zeros(n, dtype=torch.float32, device="cuda")
+    for use_src in (False, True):
+        want_idx, want_d = O.closest_hits(rays, t, src if use_src else None)
+        assert (want_idx >= 0).mean() > 0.3          # the rays do hit things
+        for v in VARIANTS:
+            hip.closest_hit_device(d_rays.data_ptr(), n, d_idx.data_ptr(), d_d.data_ptr(),
+                                   d_src_idx=d_src.data_ptr() if use_src else 0, flags=v)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_idx.cpu().numpy(), want_idx), (name, v, use_src)
+            assert np.array_equal(d_d.cpu().numpy().view(np.uint32), want_d.view(np.uint32)), (name, v, use_src)
+
+
+def test_scene_edge_cases(hip, O):
+    rays = view.Camera(40, 30).get_viewport()
+    # one triangle; a triangle nobody can hit; duplicates (ties -> lowest index); zero-area triangles
+    t0, m0 = scene.default_scene()
+    cases = {
+        "single": (t0[:1], m0[:1]),
+        "behind": (t0[:1] * np.float32(1.0) + np.array([0, 0, -50] * 3 + [0, 0, 0], dtype=np.float32), m0[:1]),
+        "dups": (np.concatenate([t0, t0, t0[::-1]]), np.concatenate([m0, m0 * np.float32(0.5), m0[::-1]])),
+    }
+    deg = np.concatenate([t0, t0[:3]]).copy()
+    deg[7, 3:9] = deg[7, 0:3].tolist() * 2
+    deg[8, 6:9] = deg[8, 3:6]
+    cases["degenerate"] = (deg, np.concatenate([m0, m0[:3]]))
+    for name, (t, m) in cases.items():
+        hip.set_scene(t, m)
+        wf = O.render_flat(rays, 40, 30, t, m)
+        wi, wa, ws = O.render_counter(rays, t, m, 3, 7)
+        for v in VARIANTS:
+            assert np.array_equal(hip.render(rays, 40, 30, 1, mode=capi.MODE_FLAT, flags=v), wf), (name, v)
+            img, acc, st = render_pt(hip, rays, 40, 30, 3, 7, flags=v)
+            assert np.array_equal(img, wi) and np.array_equal(acc, wa) and st["scans_executed"] == ws, (name, v)
+    # rays that miss everything: all-zero image (RGBA{0,0,0,0}, cpu_renderer.cpp:89), one scan per sample
+    hip.set_scene(*cases["behind"])
+    img, acc, st = render_pt(hip, rays, 40, 30, 5, 1)
+    assert not img.any() and not acc.any() and st["scans_executed"] == 40 * 30 * 5
+
+
+def test_error_behaviour(hip):
+    """Bad calls are loud errors (the C++ adapter throws std::runtime_error at the same points)."""
+    fresh = capi.Context(0)
+    rays = view.Camera(8, 8).get_viewport()
+    with pytest.raises(capi.SpathHipError, match="before a scene"):
+        fresh.render(rays, 8, 8, 1)
+    fresh.set_scene(*scene.default_scene())
+    with pytest.raises(capi.SpathHipError, match="n_samples"):
+        fresh.render(rays, 8, 8, 0)                    # the reference divides by n_samples (cpu_renderer.cpp:77)
+    with pytest.raises(capi.SpathHipError):
+        fresh.render_device(0, 64, 1, 0)               # null device pointers
+    with pytest.raises(capi.SpathHipError):
+        capi.Context(10 ** 6)                          # no such device
+    with pytest.raises(capi.SpathHipError, match="no render"):
+        capi.Context(0).stats()
+    assert fresh.render(rays, 8, 8, 1).shape == (64, 4)    # still usable after the errors
+    fresh.close()
+
+
+def test_device_path_equals_host_path_and_sharding_is_invisible(hip, O):
+    t, m = scene.open_clutter(300)
+    w, h, spp, seed = 96, 70, 3, 21
+    rays = view.Camera(w, h).get_viewport()
+    hip.set_scene(t, m)
+    want_img, want_acc, _ = render_pt(hip, rays, w, h, spp, seed)
+    assert np.array_equal(want_img, O.render_counter(rays, t, m, spp, seed)[0])
+    d_t, d_m = dev(t), dev(m)
+    st = torch.cuda.current_stream().cuda_stream
+    hip.set_scene_device(d_t.data_ptr(), d_m.data_ptr(), t.shape[0], st)
+    for world, tile_rows in [(1, 8), (2, 8), (3, 5), (8, 4), (4, 100)]:
+        plan = RowTilePlan(w, h, world, tile_rows)
+        parts_img, parts_acc = [], []
+        for rank in range(world):
+            sh = ShardedRenderer(hip, plan, rank, rays, torch.device("cuda"))
+            local = sh.render(spp, seed=seed, want_accum=True, stream=st)
+            pad = plan.max_rays()
+            bi = torch.zeros((pad, 4), dtype=torch.uint8, device="cuda"); bi[: sh.n] = local
+            ba = torch.zeros((pad, 3), dtype=torch.float32, device="cuda")
+            if sh.n:
+                ba[: sh.n] = sh.d_accum
+            parts_img.append(bi); parts_acc.append(ba)
+        torch.cuda.synchronize()
+        img = plan.assemble(torch.stack(parts_img)).cpu().numpy()
+        acc = plan.assemble(torch.stack(parts_acc)).cpu().numpy()
+        assert np.array_equal(img, want_img) and np.array_equal(acc, want_acc), (world, tile_rows)
+
+
+def test_primary_reuse_same_image_fewer_scans(hip, O):
+    t, m = scene.closed_room(500)
+    w, h, spp = 64, 40, 6
+    rays = view.Camera(w, h).get_viewport()
+    hip.set_scene(t, m)
+    for v in VARIANTS:
+        a_img, a_acc, a_st = render_pt(hip, rays, w, h, spp, 4, flags=v)
+        b_img, b_acc, b_st = render_pt(hip, rays, w, h, spp, 4, flags=v | capi.FLAG_PRIMARY_REUSE)
+        assert np.array_equal(a_img, b_img) and np.array_equal(a_acc, b_acc)
+        assert b_st["scans_executed"] == a_st["scans_executed"] - w * h * (spp - 1)
+
+
+def test_renderer_interface_mirror(hip, O, scenes):
+    """The Python twin of the reference's plugin interface: same call sequence as gl::displayFunc (main.cpp:70-83)."""
+    from spath_amd import renderer
+    r = renderer.get(80, 60, seed=5)
+    assert "HIP - Path Tracing" in r.get_description()
+    t, m = scenes["default"]
+    vp, bmp = renderer.Viewport(), renderer.Bitmap()
+    r.set_delta_mov((0.2, 0.0, -0.3)); r.set_delta_rot((0.0, 0.2, 0.0)); r.set_delta_focal(0.25)
+    r.get_viewport(vp)
+    r.render_flat(vp, t, m, 7, 1, bmp)
+    assert (bmp.res_x, bmp.res_y) == (80, 60)
+    assert np.array_equal(bmp.values, O.render_flat(vp.rays, 80, 60, t, m))
+    r.render(vp, t, m, 7, 4, bmp)
+    assert np.array_equal(bmp.values, O.render_counter(vp.rays, t, m, 4, 5)[0])
+    r.set_viewport_size(33, 21)
+    r.get_viewport(vp)
+    r.render(vp, t, m, 7, 2, bmp)
+    assert bmp.values.shape == (33 * 21, 4) and np.array_equal(bmp.values, O.render_counter(vp.rays, t, m, 2, 5)[0])
+    r.close()
+
+
+def _block_means(img, w, h, b=8):
+    x = img.reshape(h, w, 4)[: h // b * b, : w // b * b, :3].astype(np.float64)
+    return x.reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+
+
+def test_leg_c_statistical_agreement_with_reference_stream(hip, O, scenes):
+    """HIP (counter RNG) vs the reference's own LCG stream (cpu_renderer semantics with T = 8, bit-pinned to
+    the reference by leg A), default scene 320x240 at 1024 spp.  Tolerances from reference-vs-reference noise
+    (image mean 0.035 %, block-mean Linf 3.25/255, block-mean mean|d| 0.22/255)."""
+    t, m = scenes["default"]
+    w, h, spp = 320, 240, 1024
+    rays = view.Camera(w, h).get_viewport()
+    ref = O.render_mt(rays, w, h, t, m, spp, 8)
+    hip.set_scene(t, m)
+    got = hip.render(rays, w, h, spp, seed=1)
+    mg, mr = got[:, :3].astype(np.float64).mean(), ref[:, :3].astype(np.float64).mean()
+    assert abs(mg - mr) / mr <= 0.002, (mg, mr)                       # image-mean relative difference <= 0.2 %
+    d = np.abs(_block_means(got, w, h) - _block_means(ref, w, h))
+    assert d.max() <= 6.0 and d.mean() <= 0.5, (d.max(), d.mean())    # of 255
+    # and the two images agree exactly where no randomness enters: pixels whose primary ray misses everything
+    sky = (hip.render(rays, w, h, 1, mode=capi.MODE_FLAT).sum(axis=1) == 0)
+    assert sky.sum() > 1000 and not got[sky].any() and not ref[sky].any()
+
+
+def test_full_size_properties_config3(hip, O):
+    """BASELINE.json configs[2] shape (10k triangles, 1920x1080): properties that do not need the CPU oracle at
+    full size -- the exact scan and the filter scan agree bit for bit, idempotence, sharding invariance, scan
+    counts -- plus oracle spot checks on sampled pixels."""
+    t, m = scene.closed_room(10000)
+    w, h = 1920, 1080
+    rays = view.Camera(w, h).get_viewport()
+    hip.set_scene(t, m)
+    flat2 = hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=2)
+    assert hip.stats()["scans_executed"] == w * h
+    flat3 = hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=3)
+    assert np.array_equal(flat2, flat3) and np.array_equal(flat3, hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=3))
+    assert (flat2[:, :3].sum(axis=1) > 0).all()                      # closed room: every primary ray hits
+    # path trace, 2 spp: 2e11 ray-triangle pairs through both scans
+    a_img, a_acc, a_st = render_pt(hip, rays, w, h, 2, 1, flags=2)
+    b_img, b_acc, b_st = render_pt(hip, rays, w, h, 2, 1, flags=3)
+    assert np.array_equal(a_acc, b_acc) and np.array_equal(a_img, b_img)
+    assert a_st["scans_executed"] == b_st["scans_executed"]
+    assert abs(a_st["scans_executed"] - w * h * 2 * 5) <= 1e-5 * w * h * 10      # closed scene: nominal == executed (edge leaks aside)
+    # oracle on a band of rows in the middle of the image (global pixel keys)
+    p0, n = 540 * w + 700, 512
+    want_img, want_acc, _ = O.render_counter(rays, t, m, 2, 1, pix0=p0, npix=n)
+    assert np.array_equal(b_img[p0:p0 + n], want_img) and np.array_equal(b_acc[p0:p0 + n], want_acc)
+    # sharded over 8 'GPUs' == whole image
+    plan = RowTilePlan(w, h, 8, 8)
+    st = torch.cuda.current_stream().cuda_stream
+    parts = []
+    for rank in range(8):
+        sh = ShardedRenderer(hip, plan, rank, rays, torch.device("cuda"))
+        loc = sh.render(2, seed=1, flags=3, stream=st)
+        buf = torch.zeros((plan.max_rays(), 4), dtype=torch.uint8, device="cuda"); buf[: sh.n] = loc
+        parts.append(buf)
+    torch.cuda.synchronize()
+    assert np.array_equal(plan.assemble(torch.stack(parts)).cpu().numpy(), b_img)
+
+
+def test_config2_default_720p_against_oracle(hip, O, scenes):
+    """BASELINE.json configs[1]: default scene, 1280x720, 64 spp on 1 MI355X, leg B at full size."""
+    t, m = scenes["default"]
+    w, h, spp = 1280, 720, 64
+    rays = view.Camera(w, h).get_viewport()
+    hip.set_scene(t, m)
+    img, acc, st = render_pt(hip, rays, w, h, spp, 1)
+    want_img, want_acc, scans = O.render_counter(rays, t, m, spp, 1)
+    assert np.abs(acc - want_acc).max() <= ACCUM_LINF_TOLERANCE
+    assert np.array_equal(img, want_img) and st["scans_executed"] == scans
