@@ -36,12 +36,33 @@ BYTES_PER_TEST = 48          # sizeof(geom::triangle)
 FLOPS_PER_TEST = 52
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("SPATH_CPU_THREADS")
+    return int(env) if env else n
+
+
 def cpu_baseline(tris, mats, args):
     """The reference's cpu_renderer timed on this box's host cores on a bounded sample of the same scene."""
     import numpy as np
     from oracle import oracle as O
     from spath_amd import view
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     w, h, spp = args.cpu_w, args.cpu_h, args.cpu_spp
     nominal = w * h * spp * 5
     if O.have_ref():

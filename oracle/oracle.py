@@ -174,14 +174,19 @@ def ref_run(mode, w, h, spp=1, tris=None, mats=None, threads=8, moves=(), rays=N
             rp = os.path.join(td, "rays.bin")
             np.ascontiguousarray(rays, dtype=F).tofile(rp)
             cmd += ["rays", rp]
-        env = dict(os.environ, ORACLE_THREADS=str(threads))
+        # a profiler wrapped around the caller (rocprofv3 LD_PRELOADs its tool) must not follow into the CPU child
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
+        env["ORACLE_THREADS"] = str(threads)
         pr = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True)
         if mode == "viewport":
             res = np.fromfile(outp, dtype=F).reshape(w * h, 6)
         else:
             res = np.fromfile(outp, dtype=np.uint8).reshape(w * h, 4)
         if return_info:
-            info = json.loads(pr.stderr.decode().strip().splitlines()[-1]) if mode != "viewport" else {}
+            info = {}
+            for line in pr.stderr.decode(errors="replace").splitlines():
+                if line.startswith('{"mode"'):
+                    info = json.loads(line)
             return res, info
         return res
 
