@@ -1,0 +1,19 @@
+// hip_renderer -- the MI355X backend as a peer of cpu_renderer / cl_renderer / vk_renderer.
+// Same shape as the reference's per-backend headers (src/cpu_renderer.h:23-25): one factory.
+#pragma once
+
+#include "spath_iface.h"
+
+namespace hip_renderer {
+	// Returns a new renderer owned by the caller (the reference wraps it in std::unique_ptr,
+	// src/main.cpp:242-244).  Throws std::runtime_error when no usable HIP device exists, like the
+	// reference's GPU peers do from their constructors (src/cl_renderer.cpp:155-187).
+	extern scene::renderer* get(const int w, const int h);
+
+	// Optional knobs of this backend (not part of the reference interface): the RNG seed of the next
+	// frames and the C-ABI flags word (kernel variant, primary-hit reuse; see include/spath_hip.h).
+	extern void set_seed(scene::renderer* r, unsigned long long seed);
+	extern void set_flags(scene::renderer* r, int flags);
+	// kernel milliseconds and closest-hit scans of the last frame (0 if r is not a hip renderer)
+	extern bool last_stats(scene::renderer* r, double* kernel_ms, unsigned long long* scans);
+}

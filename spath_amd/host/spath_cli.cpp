@@ -1,0 +1,130 @@
+// Headless front end for the renderer plugin interface: what the reference's GLUT shell does per frame
+// (src/main.cpp:70-83: get_viewport -> render / render_flat -> show the bitmap), minus the window.
+// Keys of the interactive shell become flags: camera moves (w/a/s/d, mouse -> --mov/--rot/--focal),
+// '+'/'-' -> --spp, 'p' -> --mode.  The image goes to a binary PPM or a raw RGBA file.
+//
+//   spath_cli [--scene default|FILE.bin] [--w 640 --h 480] [--spp 128] [--mode pt|flat]
+//             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--out image.ppm|image.rgba] [--frames n]
+#include "hip_renderer.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+geom::vec3 sub(const geom::vec3& a, const geom::vec3& b) { return geom::vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+void set_flat_normal(geom::triangle& t) {   // unit((v1-v0) x (v2-v0)), the caller's job in the reference too (main.cpp:214-215)
+	const geom::vec3 a = sub(t.v1, t.v0), b = sub(t.v2, t.v0);
+	const geom::vec3 c(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+	const real l = std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z);
+	t.n = geom::vec3(c.x / l, c.y / l, c.z / l);
+}
+
+// the demo scene of the reference (values: SURVEY.md Appendix C): pyramid face, floor, area light, back wall
+void default_scene(std::vector<geom::triangle>& t, std::vector<scene::material>& m) {
+	static const float v[7][9] = {
+		{ 0, 0, 1, 0.5f, -0.5f, 0, -0.5f, -0.5f, 0 },
+		{ 20, -1, 20, -20, -1, -20, -20, -1, 20 }, { 20, -1, 20, 20, -1, -20, -20, -1, -20 },
+		{ 0.75f, 0.75f, 0.75f, -0.75f, 0.75f, 0.75f, 0.75f, 0.75f, -0.75f }, { -0.75f, 0.75f, 0.75f, -0.75f, 0.75f, -0.75f, 0.75f, 0.75f, -0.75f },
+		{ 1.25f, 0.5f, 1, 1.25f, -1, 1, -1.25f, -1, 1 }, { 1.25f, 0.5f, 1, -1.25f, -1, 1, -1.25f, 0.5f, 1 } };
+	static const float refl[7][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 1, 1 }, { 1, 1, 1 }, { 1, 1, 1 }, { 1, 1, 1 } };
+	t.resize(7); m.resize(7);
+	for (int i = 0; i < 7; ++i) {
+		t[i].v0 = geom::vec3(v[i][0], v[i][1], v[i][2]); t[i].v1 = geom::vec3(v[i][3], v[i][4], v[i][5]); t[i].v2 = geom::vec3(v[i][6], v[i][7], v[i][8]);
+		set_flat_normal(t[i]);
+		m[i].reflectance_color = geom::vec3(refl[i][0], refl[i][1], refl[i][2]);
+		const float e = (i == 3 || i == 4) ? 1.0f : 0.0f;
+		m[i].emittance_color = geom::vec3(e, e, e);
+	}
+}
+
+bool load_scene(const char* path, std::vector<geom::triangle>& t, std::vector<scene::material>& m) {   // 'SPSC' file of spath_amd/scene.py
+	FILE* f = std::fopen(path, "rb");
+	if (!f) return false;
+	uint32_t hdr[2];
+	bool ok = std::fread(hdr, 4, 2, f) == 2 && hdr[0] == 0x43535053u;
+	if (ok) {
+		t.resize(hdr[1]); m.resize(hdr[1]);
+		ok = std::fread(t.data(), sizeof(geom::triangle), hdr[1], f) == hdr[1] && std::fread(m.data(), sizeof(scene::material), hdr[1], f) == hdr[1];
+	}
+	std::fclose(f);
+	return ok;
+}
+
+} // namespace
+
+int main(int argc, char** argv) {
+	try {
+		std::string scene_arg = "default", mode = "pt", out_path;
+		int w = 640, h = 480, frames = 1, flags = 0;                 // window default of the reference (main.cpp:238-239)
+		size_t spp = 128;                                            // main.cpp:44
+		unsigned long long seed = 1;
+		std::vector<std::pair<char, geom::vec3> > moves;
+		for (int i = 1; i < argc; ++i) {
+			const std::string k = argv[i];
+			auto need = [&](int n) { if (i + n >= argc) throw std::runtime_error("missing value after " + k); };
+			if (k == "--scene") { need(1); scene_arg = argv[++i]; }
+			else if (k == "--w") { need(1); w = std::atoi(argv[++i]); }
+			else if (k == "--h") { need(1); h = std::atoi(argv[++i]); }
+			else if (k == "--spp") { need(1); spp = (size_t)std::atoll(argv[++i]); }
+			else if (k == "--mode") { need(1); mode = argv[++i]; }
+			else if (k == "--seed") { need(1); seed = std::strtoull(argv[++i], 0, 0); }
+			else if (k == "--flags") { need(1); flags = std::atoi(argv[++i]); }
+			else if (k == "--frames") { need(1); frames = std::atoi(argv[++i]); }
+			else if (k == "--out") { need(1); out_path = argv[++i]; }
+			else if (k == "--mov" || k == "--rot") { need(3); moves.push_back(std::make_pair(k[2], geom::vec3(std::atof(argv[i + 1]), std::atof(argv[i + 2]), std::atof(argv[i + 3])))); i += 3; }
+			else if (k == "--focal") { need(1); moves.push_back(std::make_pair('f', geom::vec3(std::atof(argv[++i]), 0, 0))); }
+			else throw std::runtime_error("unknown argument " + k);
+		}
+		std::vector<geom::triangle> tris;
+		std::vector<scene::material> mats;
+		if (scene_arg == "default") default_scene(tris, mats);
+		else if (!load_scene(scene_arg.c_str(), tris, mats)) throw std::runtime_error("cannot read scene file " + scene_arg);
+
+		std::unique_ptr<scene::renderer> r(hip_renderer::get(w, h));     // main.cpp:242-244
+		hip_renderer::set_seed(r.get(), seed);
+		hip_renderer::set_flags(r.get(), flags);
+		std::printf("Current renderer: %s\n", r->get_description());     // main.cpp:30-32
+		for (size_t k = 0; k < moves.size(); ++k) {
+			if (moves[k].first == 'm') r->set_delta_mov(moves[k].second);
+			else if (moves[k].first == 'r') r->set_delta_rot(moves[k].second);
+			else r->set_delta_focal(moves[k].second.x);
+		}
+		view::viewport vp;
+		scene::bitmap bmp;
+		for (int f = 0; f < frames; ++f) {
+			const auto t0 = std::chrono::steady_clock::now();
+			r->get_viewport(vp);                                         // main.cpp:74
+			if (mode == "pt") r->render(vp, tris.data(), mats.data(), tris.size(), spp, bmp);
+			else r->render_flat(vp, tris.data(), mats.data(), tris.size(), spp, bmp);
+			const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			double kms = 0; unsigned long long scans = 0;
+			hip_renderer::last_stats(r.get(), &kms, &scans);
+			std::printf("Done (%.3fs) frame %d: %dx%d, %zu spp, %zu triangles, kernel %.3f ms, %llu scans, %.1f Mray/s nominal\n", s, f, w, h,
+			            spp, tris.size(), kms, scans, mode == "pt" ? (double)w * h * spp * 5 / s / 1e6 : (double)w * h / s / 1e6);
+		}
+		if (!out_path.empty()) {
+			FILE* o = std::fopen(out_path.c_str(), "wb");
+			if (!o) throw std::runtime_error("cannot write " + out_path);
+			if (out_path.size() > 4 && out_path.substr(out_path.size() - 4) == ".ppm") {
+				std::fprintf(o, "P6\n%zu %zu\n255\n", bmp.res_x, bmp.res_y);
+				for (size_t i = 0; i < bmp.values.size(); ++i) std::fwrite(&bmp.values[i], 1, 3, o);   // row 0 = top, as stored
+			} else {
+				std::fwrite(bmp.values.data(), sizeof(scene::RGBA), bmp.values.size(), o);
+			}
+			std::fclose(o);
+		}
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "Exception: %s\n", e.what());               // main.cpp:263-264
+		return 1;
+	}
+	return 0;
+}
