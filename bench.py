@@ -115,18 +115,25 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a 1-GPU box: SPATH_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
+    # ranks on one device); the real multi-GPU run is one rank per GPU over RCCL ("nccl" backend on ROCm)
+    rehearsal = os.environ.get("SPATH_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     W, H, SPP, NT = args.width, args.height, args.spp, args.tris
     tris, mats = scene.closed_room(NT)
     rays = view.Camera(W, H).get_viewport()
     plan = RowTilePlan(W, H, world, args.tile_rows)
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     variants = capi.kernel_variants()
     if args.kernel not in variants:
         raise SystemExit(f"unknown --kernel {args.kernel}; have {sorted(variants)}")
@@ -147,7 +154,10 @@ def main():
         local = shard.render(SPP, seed=1, mode=capi.MODE_PT, flags=flags, stream=stream)
         if i_timed is not None:
             ev[i_timed][1].record()
-        image = gather_to_root(local, plan, rank) if world > 1 else local
+        if world > 1:
+            image = gather_to_root(local.cpu() if rehearsal else local, plan, rank)
+        else:
+            image = local
 
     def fence():
         torch.cuda.synchronize()
@@ -166,10 +176,11 @@ def main():
     st = ctx.stats()                       # figures of the last launch on this rank
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if rehearsal else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([float(st["scans_executed"]), max(kernel_ms) if kernel_ms else 0.0], dtype=torch.float64, device=dev)
+        s = torch.tensor([float(st["scans_executed"]), max(kernel_ms) if kernel_ms else 0.0], dtype=torch.float64, device=cdev)
         s_sum = s.clone(); dist.all_reduce(s_sum, op=dist.ReduceOp.SUM)
         s_max = s.clone(); dist.all_reduce(s_max, op=dist.ReduceOp.MAX)
         scans_per_step, kern_ms_max = float(s_sum[0].item()), float(s_max[1].item())
@@ -216,6 +227,8 @@ def main():
                 "arithmetic": "strict (no FMA contraction, IEEE divide): bit-identical to the CPU oracle",
             },
             "scans_per_step": scans_per_step,
+            # per-channel sums of the assembled RGBA8 frame: identical for every --gpus N (pixel-keyed RNG)
+            "image_sum_rgb": [int(x) for x in image[:, :3].to(torch.int64).sum(dim=0).tolist()],
             "nominal_rays_per_step": nominal,
             "roofline": {
                 "bound": "hbm",
@@ -224,7 +237,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "k_pt",
+                "kernel": "k_pt_filter<R>" if st["kernel_variant"] >= 3 else "k_pt<variant>",
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
                 "algorithmic_bytes_per_launch": my_scans * NT * BYTES_PER_TEST,
                 "note": "effective (logical-stream) bandwidth of rank 0's launch; exceeds HBM peak because triangles are reused from LDS/L2",
