@@ -1,9 +1,11 @@
 // Two-stage closest-hit scan ("rpl_filter"): a cheap CONSERVATIVE reject per (ray, triangle),
 // the reference's exact Moeller-Trumbore only for the rare survivors.  Bit-identical results.
 //
-// Stage 1 (every pair, 11 VALU): is the ray outside the slab spanned by the two lines through v0 and
-// through v1 that run parallel to edge2?  With w = unit(e2), P = pos x dir (ray moment, per ray),
-// M0 = w x v0, M1 = w x v1 (per triangle):
+// Stage 1 (every pair, 11 VALU): is the ray outside the slab spanned by the two lines that run parallel
+// to one edge of the triangle, one through that edge and one through the opposite vertex?  Written here
+// for edge2 (lines through v0 and v1); k_repack_filter picks the longest edge, i.e. the narrowest slab,
+// and the same argument holds for the v and u+v slabs.  With w = unit(e2),
+// P = pos x dir (ray moment, per ray), M0 = w x v0, M1 = w x v1 (per triangle):
 //     g0 = (pos - v0) . (dir x w) = w.P - dir.M0        g1 = (pos - v1) . (dir x w) = w.P - dir.M1
 // g0 is the reference's s.h (geom.h:208) up to the factor |e2|, and g0 - g1 its a (geom.h:203).
 // geom::ray_intersect accepts only if u = f*(s.h) lies in [0,1] (geom.h:209), i.e. only if g0 and g1
@@ -32,7 +34,8 @@
 
 namespace sp {
 
-constexpr int kQCap = 32;   // queue entries per lane (u16: slot<<8 | index in tile)
+constexpr uint32_t kU = 4;  // triangles per filter-loop iteration (one branch per kU x R tests)
+constexpr int kQCap = 24;   // queue entries per lane (u16: slot<<8 | index in tile); 12 KB, keeps 4 workgroups per CU
 
 // filter record: 48 B = 3 x float4, produced by k_repack_filter
 //   q0 = w.x w.y w.z M0.x   q1 = M0.y M0.z M1.x M1.y   q2 = M1.z 0 0 0
@@ -47,14 +50,27 @@ __global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__
 		return;
 	}
 	const float* t = tris + (size_t)i * 12;
-	const double v0x = t[0], v0y = t[1], v0z = t[2], v1x = t[3], v1y = t[4], v1z = t[5];
-	// e2 exactly as the reference rounds it (geom.h:201), then normalised in double
-	const double e2x = (double)(t[6] - t[0]), e2y = (double)(t[7] - t[1]), e2z = (double)(t[8] - t[2]);
-	const double len = sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
-	const float wx = (float)(e2x / len), wy = (float)(e2y / len), wz = (float)(e2z / len);   // NaN for a degenerate edge: always survives
+	// e1, e2 exactly as the reference rounds them (geom.h:200-201); c = e2 - e1 is the third edge (v1 -> v2)
+	const double A[3] = { t[0], t[1], t[2] }, B[3] = { t[3], t[4], t[5] }, C[3] = { t[6], t[7], t[8] };
+	const double e1[3] = { (double)(t[3] - t[0]), (double)(t[4] - t[1]), (double)(t[5] - t[2]) };
+	const double e2[3] = { (double)(t[6] - t[0]), (double)(t[7] - t[1]), (double)(t[8] - t[2]) };
+	const double c[3] = { e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2] };
+	const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+	const double l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+	const double lc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+	// the narrowest of the three slabs that contain the triangle = the one along its LONGEST edge:
+	//   along e2 through v0, apex v1  <->  u in [0,1]      (geom.h:209)
+	//   along e1 through v0, apex v2  <->  v in [0,1]      (geom.h:213: v >= 0, and v <= u+v <= 1)
+	//   along c  through v1, apex v0  <->  u+v in [0,1]    (geom.h:213: u+v <= 1, and u, v >= 0)
+	const double* w3; const double* p0; const double* p1; double len2;
+	if (l2 >= l1 && l2 >= lc) { w3 = e2; p0 = A; p1 = B; len2 = l2; }
+	else if (l1 >= lc)        { w3 = e1; p0 = A; p1 = C; len2 = l1; }
+	else                      { w3 = c;  p0 = B; p1 = A; len2 = lc; }
+	const double len = sqrt(len2);
+	const float wx = (float)(w3[0] / len), wy = (float)(w3[1] / len), wz = (float)(w3[2] / len);   // NaN for a degenerate triangle: always survives
 	const double dwx = wx, dwy = wy, dwz = wz;
-	const float m0x = (float)(dwy * v0z - dwz * v0y), m0y = (float)(dwz * v0x - dwx * v0z), m0z = (float)(dwx * v0y - dwy * v0x);
-	const float m1x = (float)(dwy * v1z - dwz * v1y), m1y = (float)(dwz * v1x - dwx * v1z), m1z = (float)(dwx * v1y - dwy * v1x);
+	const float m0x = (float)(dwy * p0[2] - dwz * p0[1]), m0y = (float)(dwz * p0[0] - dwx * p0[2]), m0z = (float)(dwx * p0[1] - dwy * p0[0]);
+	const float m1x = (float)(dwy * p1[2] - dwz * p1[1]), m1y = (float)(dwz * p1[0] - dwx * p1[2]), m1z = (float)(dwx * p1[1] - dwy * p1[0]);
 	filt[(size_t)i * 3 + 0] = make_float4(wx, wy, wz, m0x);
 	filt[(size_t)i * 3 + 1] = make_float4(m0y, m0z, m1x, m1y);
 	filt[(size_t)i * 3 + 2] = make_float4(m1z, 0.0f, 0.0f, 0.0f);
@@ -90,6 +106,15 @@ SP_DEV void exact_range(const float4* __restrict__ scan, uint32_t lo, uint32_t h
 			bi[r] = take ? (int)j : bi[r];
 		}
 	}
+}
+
+// one 12 KB tile global -> LDS: 3 x 16 B per thread, asynchronous (counts on vmcnt)
+SP_DEV void tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, uint32_t wbase) {
+	typedef __attribute__((address_space(1))) const void* gptr_t;
+	typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+	for (int p = 0; p < 3; ++p)
+		__builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + tid), (lptr_t)(dst + p * 256 + wbase), 16, 0, 0);
 }
 
 // stage 1 for one (triangle record, ray): true = survivor
@@ -131,49 +156,50 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		bi[r] = -1;
 	}
 
-	float4 p0 = filt[tid], p1 = filt[256 + tid], p2 = filt[512 + tid];
-	__syncthreads();
-	sm[tid] = p0; sm[256 + tid] = p1; sm[512 + tid] = p2;
-	__syncthreads();
+	// tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write; each wave
+	// instruction lands 64 lanes x 16 B contiguously at a wave-uniform LDS base, which is this layout
+	const uint32_t wbase = tid & ~63u;
+	__syncthreads();                            // readers of the previous scan are done with sm
+	tile_dma(filt, sm, tid, wbase);
+	__syncthreads();                            // (the barrier's fence waits for the DMA: vmcnt(0))
 	for (uint32_t t = 0; t < ntiles; ++t) {
 		const float4* cur = sm + (t & 1u) * kTileQ;
-		const bool more = (t + 1 < ntiles);
-		const float4* nsrc = filt + (size_t)(more ? t + 1 : t) * kTileQ;
-		p0 = nsrc[tid]; p1 = nsrc[256 + tid]; p2 = nsrc[512 + tid];
 		const uint32_t left = n_tris - t * kTile;
 		const uint32_t cnt = left < (uint32_t)kTile ? left : (uint32_t)kTile;
-		const uint32_t cnt2 = (cnt + 1u) & ~1u;   // pairs; an odd tail reads one padding record (w = M = 0: survives,
-		                                          // and is then rejected by the exact stage: zero exact record)
+		// groups of kU triangles; a ragged tail reads padding records (w = M = 0: they survive stage 1 and are
+		// then rejected by the exact stage, whose padding record has a = 0)
+		const uint32_t qend = ((cnt + kU - 1u) / kU) * (3u * kU);
 		const uint32_t base = t * kTile;
 		uint32_t qn = 0;                          // survivors of this lane in this tile (may exceed kQCap: overflow)
-		for (uint32_t j = 0; j < cnt2; j += 2) {
-			const float4 a0 = cur[3 * j + 0], a1 = cur[3 * j + 1];
-			const float a2 = cur[3 * j + 2].x;
-			const float4 b0 = cur[3 * j + 3], b1 = cur[3 * j + 4];
-			const float b2 = cur[3 * j + 5].x;
-			bool sa[R], sb[R];
+		for (uint32_t q = 0; q < qend; q += 3u * kU) {      // q: float4 offset of the group, wave-uniform (scalar loop)
+			float4 a0[kU], a1[kU];
+			float a2[kU];
+#pragma unroll
+			for (int u = 0; u < (int)kU; ++u) { a0[u] = cur[q + 3 * u]; a1[u] = cur[q + 3 * u + 1]; a2[u] = cur[q + 3 * u + 2].x; }
+			bool sv[kU][R];
 			bool any = false;
 #pragma unroll
-			for (int r = 0; r < R; ++r) {
-				sa[r] = slab_survives(a0, a1, a2, P[r], s.dir[r], Dq[r]);
-				sb[r] = slab_survives(b0, b1, b2, P[r], s.dir[r], Dq[r]);
-				any |= sa[r] | sb[r];
-			}
+			for (int u = 0; u < (int)kU; ++u)
+#pragma unroll
+				for (int r = 0; r < R; ++r) {
+					sv[u][r] = slab_survives(a0[u], a1[u], a2[u], P[r], s.dir[r], Dq[r]);
+					any |= sv[u][r];
+				}
 			if (any) {                            // rare: queue the survivors, triangle-major so the order stays ascending
+				const uint32_t j0 = q / 3u;
 #pragma unroll
-				for (int r = 0; r < R; ++r) if (sa[r]) {
-					const uint32_t e = qn < (uint32_t)kQCap ? qn : (uint32_t)kQCap - 1u;
-					qs[e * 256 + tid] = (unsigned short)((r << 8) | j);
-					++qn;
-				}
+				for (int u = 0; u < (int)kU; ++u)
 #pragma unroll
-				for (int r = 0; r < R; ++r) if (sb[r]) {
-					const uint32_t e = qn < (uint32_t)kQCap ? qn : (uint32_t)kQCap - 1u;
-					qs[e * 256 + tid] = (unsigned short)((r << 8) | (j + 1));
-					++qn;
-				}
+					for (int r = 0; r < R; ++r) if (sv[u][r]) {
+						const uint32_t e = qn < (uint32_t)kQCap ? qn : (uint32_t)kQCap - 1u;
+						qs[e * 256 + tid] = (unsigned short)((r << 8) | (j0 + u));
+						++qn;
+					}
 			}
 		}
+		// the next tile streams in while the survivors are processed (issued here, not before the filter loop:
+		// the compiler orders every LDS read behind an outstanding LDS-DMA with s_waitcnt vmcnt(0))
+		if (t + 1 < ntiles) tile_dma(filt + (size_t)(t + 1) * kTileQ, sm + ((t + 1) & 1u) * kTileQ, tid, wbase);
 		// ---- stage 2: exact tests of this tile's survivors, in queue (= index) order
 		if (__builtin_expect(__any(qn > (uint32_t)kQCap), 0)) {
 			// some lane overflowed its queue: the whole wave re-scans the tile exactly (rare: scenes made of
@@ -200,9 +226,7 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 				}
 			}
 		}
-		float4* nxt = sm + ((t + 1) & 1u) * kTileQ;
-		nxt[tid] = p0; nxt[256 + tid] = p1; nxt[512 + tid] = p2;
-		__syncthreads();
+		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
 	}
 }
 
