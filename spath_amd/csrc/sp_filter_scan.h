@@ -185,7 +185,12 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 					sv[u][r] = slab_survives(a0[u], a1[u], a2[u], P[r], s.dir[r], Dq[r]);
 					any |= sv[u][r];
 				}
+#ifdef SP_ABLATE_NOPUSH
+			qn += any ? 1u : 0u;                  // timing experiment only (wrong images): keep the filter alive, skip the queue
+			if (false) {
+#else
 			if (any) {                            // rare: queue the survivors, triangle-major so the order stays ascending
+#endif
 				const uint32_t j0 = q / 3u;
 #pragma unroll
 				for (int u = 0; u < (int)kU; ++u)
@@ -200,6 +205,17 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		// the next tile streams in while the survivors are processed (issued here, not before the filter loop:
 		// the compiler orders every LDS read behind an outstanding LDS-DMA with s_waitcnt vmcnt(0))
 		if (t + 1 < ntiles) tile_dma(filt + (size_t)(t + 1) * kTileQ, sm + ((t + 1) & 1u) * kTileQ, tid, wbase);
+#ifdef SP_FILTER_STATS
+		{   // experiment build only: survivors, exact rounds, tiles per wave -> a.scans[1..3]
+			uint32_t v = qn, mx = qn;
+			for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); const uint32_t o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
+			if ((tid & 63u) == 0) { atomicAdd(a.scans + 1, (unsigned long long)v); atomicAdd(a.scans + 2, (unsigned long long)mx); atomicAdd(a.scans + 3, 1ull); }
+		}
+#endif
+#ifdef SP_ABLATE_NOFLUSH
+		if (qn == 0x0fffffffu) bi[0] = 1;         // timing experiment only (wrong images): keep qn alive, skip the exact stage
+		qn = 0;
+#endif
 		// ---- stage 2: exact tests of this tile's survivors, in queue (= index) order
 		if (__builtin_expect(__any(qn > (uint32_t)kQCap), 0)) {
 			// some lane overflowed its queue: the whole wave re-scans the tile exactly (rare: scenes made of

@@ -107,7 +107,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	if (mode == kModeHits && !d_accum) return fail(c, SPHIP_E_INVALID, "null distance output");
 	if (mode == SPHIP_MODE_PT && (n_samples == 0 || n_samples > 0x7fffffffull))
 		return fail(c, SPHIP_E_INVALID, "n_samples must be in [1, 2^31) (the reference divides by it, cpu_renderer.cpp:77)");
-	int rc = ensure(c, c->counter, sizeof(unsigned long long));
+	int rc = ensure(c, c->counter, 8 * sizeof(unsigned long long));
 	if (rc) return rc;
 
 	sp::KArgs a{};
@@ -132,7 +132,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	a.inv_n = (float)(1.0 / (double)(n_samples ? n_samples : 1));      // cpu_renderer.cpp:77
 
 	const int variant = pick_variant(flags, c->n_tris);
-	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(unsigned long long), st));
+	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, 8 * sizeof(unsigned long long), st));
 	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
 	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
 	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray
@@ -315,6 +315,14 @@ int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 	HIP_TRY(c, hipMemcpyAsync(&scans, c->counter.p, sizeof scans, hipMemcpyDeviceToHost, c->last_stream));
 	HIP_TRY(c, hipStreamSynchronize(c->last_stream));
 	c->stats.scans_executed = scans;
+#ifdef SP_FILTER_STATS
+	{
+		unsigned long long x[4] = {0, 0, 0, 0};
+		(void)hipMemcpy(x, c->counter.p, sizeof x, hipMemcpyDeviceToHost);
+		fprintf(stderr, "[filter stats] survivors=%llu rounds(sum of per-wave max)=%llu wave_tiles=%llu -> survivors/lane/tile=%.3f rounds/tile=%.2f\n",
+		        x[1], x[2], x[3], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3]);
+	}
+#endif
 	*out = c->stats;
 	return SPHIP_OK;
 }
