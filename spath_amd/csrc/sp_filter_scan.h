@@ -302,25 +302,31 @@ __global__ void __launch_bounds__(256) k_flat_filter(const KArgs a, const float4
 	wave_add_scans(a.scans, nsc);
 }
 
-// ---- renderer::render with the filter scan; R pixels per lane, all R paths advance in lock-step.
+// ---- renderer::render with the filter scan; R paths per lane advance in lock-step.
+// SPLIT = false: the R slots of a lane are R different pixels (ray k0 + r*256).
+// SPLIT = true : the R slots are R CONSECUTIVE SAMPLES of the same pixel (sample smp*R + r); their results are
+//                added to the accumulator in sample order, so the sum is the reference's (cpu_renderer.cpp:74-76).
+//                A workgroup then covers 256 pixels instead of 256*R: small shards still fill the chip.
 // Per-path history (hit index and cos(theta) per depth) and the per-pixel accumulator are parked in a
-// global work buffer between scans instead of being held in VGPRs through the scan loop: 52 B per pixel,
+// global work buffer between scans instead of being held in VGPRs through the scan loop: 52 B per slot,
 // touched once per bounce, against ~10^5 VALU instructions per bounce.
 //   work layout: hist[depth][k] = {idx, cos bits} (8 B), then acc[c][k] (3 floats), k < n_work
-template <int R>
+template <int R, bool SPLIT>
 __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, const float4* __restrict__ filt, const unsigned int* __restrict__ bounds,
                                                    int2* __restrict__ hist, float* __restrict__ acc, uint32_t n_work) {
 	const float rv = __uint_as_float(bounds[0]);
 	const uint32_t tid = threadIdx.x;
-	const uint32_t k0 = blockIdx.x * (256u * R) + tid;       // slot r handles ray k0 + r*256
+	const uint32_t k0 = blockIdx.x * (256u * R) + tid;       // work-buffer slot of path r: k0 + r*256
+	const uint32_t kstep = SPLIT ? 0u : 256u;                // ray index of slot r: kr0 + r*kstep
+	const uint32_t kr0 = SPLIT ? blockIdx.x * 256u + tid : k0;
 	uint32_t pixel[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		const uint32_t k = k0 + r * 256u;
+		const uint32_t k = kr0 + r * kstep;
 		const uint32_t kk = k < a.n_rays ? k : a.n_rays - 1;
 		pixel[r] = (uint32_t)shard_pixel(a, kk);
 #pragma unroll
-		for (int c = 0; c < 3; ++c) acc[(size_t)c * n_work + k] = 0.0f;
+		for (int c = 0; c < 3; ++c) acc[(size_t)c * n_work + k0 + r * 256u] = 0.0f;
 	}
 	const bool reuse = (a.flags & 0x100u) != 0;
 	uint32_t my_scans = 0;
@@ -329,26 +335,34 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 		RaySlots<R> s;
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
-			const uint32_t k = k0 + r * 256u;
+			const uint32_t k = kr0 + r * kstep;
 			const bool valid = k < a.n_rays;
 			const float* pr = a.rays + (size_t)(valid ? k : a.n_rays - 1) * 6;
 			s.o[r] = mk3(pr[0], pr[1], pr[2]); s.dir[r] = mk3(pr[3], pr[4], pr[5]);
-			s.src[r] = -1; s.act[r] = valid;
-			my_scans += valid ? 1u : 0u;
+			s.src[r] = -1; s.act[r] = valid && (!SPLIT || r == 0);
+			my_scans += s.act[r] ? 1u : 0u;
 		}
 		scan_filter<R>(a, filt, rv, s, pd, pi);
+		if (SPLIT) {
+#pragma unroll
+			for (int r = 1; r < R; ++r) { pd[r] = pd[0]; pi[r] = pi[0]; }
+		}
 	}
 
-	for (uint32_t smp = 0; smp < a.n_samples; ++smp) {
+	const uint32_t n_iter = SPLIT ? (a.n_samples + R - 1) / R : a.n_samples;
+	for (uint32_t it = 0; it < n_iter; ++it) {
 		RaySlots<R> s;
 		int nh[R];                       // surface hits of this path so far
+		uint32_t smp[R];
+		bool live[R];                    // this slot carries a sample in this iteration
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
-			const uint32_t k = k0 + r * 256u;
-			const bool valid = k < a.n_rays;
-			const float* pr = a.rays + (size_t)(valid ? k : a.n_rays - 1) * 6;
+			const uint32_t k = kr0 + r * kstep;
+			smp[r] = SPLIT ? it * R + r : it;
+			live[r] = (k < a.n_rays) && (smp[r] < a.n_samples);
+			const float* pr = a.rays + (size_t)(k < a.n_rays ? k : a.n_rays - 1) * 6;
 			s.o[r] = mk3(pr[0], pr[1], pr[2]); s.dir[r] = mk3(pr[3], pr[4], pr[5]);
-			s.src[r] = -1; s.act[r] = valid;
+			s.src[r] = -1; s.act[r] = live[r];
 			nh[r] = 0;
 		}
 #pragma unroll 1
@@ -374,7 +388,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 					f3 n = mk3(tn[0], tn[1], tn[2]);
 					if (dot3(n, s.dir[r]) > 0.0f) n = scale3(n, -1.0f);
 					double r1, r2;
-					philox_uniforms(a.seed, pixel[r], smp, (uint32_t)depth, &r1, &r2);
+					philox_uniforms(a.seed, pixel[r], smp[r], (uint32_t)depth, &r1, &r2);
 					const f3 nd = rand_unit_vec(n, r1, r2);
 					const float ct = dot3(nd, n);
 					s.o[r] = add3(s.o[r], scale3(s.dir[r], bd[r]));
@@ -388,27 +402,33 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 		}
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
-			const uint32_t k = k0 + r * 256u;
+			const uint32_t kw = k0 + r * 256u;
 			f3 rec = mk3(0.0f, 0.0f, 0.0f);
 			for (int d = nh[r] - 1; d >= 0; --d) {
-				const int2 hc = hist[(size_t)d * n_work + k];
+				const int2 hc = hist[(size_t)d * n_work + kw];
 				const float* m = a.mats + (size_t)hc.x * 6;
 				const f3 brdf = scale3(mk3(m[0], m[1], m[2]), kInvPi);
 				const f3 e = mk3(m[3], m[4], m[5]);
 				rec = add3(e, scale3(scale3(mul3(brdf, rec), __uint_as_float((uint32_t)hc.y)), kInvP));
 			}
+			// cpu_renderer.cpp:75 accum += sample, in sample order: with SPLIT the slots are consecutive samples of one
+			// pixel and are added to slot 0's accumulator one after the other (this loop is unrolled in order)
+			if (live[r]) {
+				const uint32_t ka = SPLIT ? k0 : kw;
 #pragma unroll
-			for (int c = 0; c < 3; ++c) {
-				float* p = acc + (size_t)c * n_work + k;
-				*p = *p + (c == 0 ? rec.x : c == 1 ? rec.y : rec.z);          // cpu_renderer.cpp:75, same order
+				for (int c = 0; c < 3; ++c) {
+					float* p = acc + (size_t)c * n_work + ka;
+					*p = *p + (c == 0 ? rec.x : c == 1 ? rec.y : rec.z);
+				}
 			}
 		}
 	}
 #pragma unroll
-	for (int r = 0; r < R; ++r) {
-		const uint32_t k = k0 + r * 256u;
+	for (int r = 0; r < (SPLIT ? 1 : R); ++r) {
+		const uint32_t k = kr0 + r * kstep;
+		const uint32_t kw = k0 + r * 256u;
 		if (k < a.n_rays) {
-			const f3 av = scale3(mk3(acc[k], acc[(size_t)n_work + k], acc[(size_t)2 * n_work + k]), a.inv_n);
+			const f3 av = scale3(mk3(acc[kw], acc[(size_t)n_work + kw], acc[(size_t)2 * n_work + kw]), a.inv_n);
 			a.out_rgba[k] = vec3_rgba(mk3(clamp01(av.x), clamp01(av.y), clamp01(av.z)));
 			if (a.out_accum) {
 				a.out_accum[(size_t)k * 3 + 0] = av.x;

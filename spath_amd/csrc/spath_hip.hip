@@ -68,13 +68,20 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 	return SPHIP_OK;
 }
 
-constexpr int kNumVariants = 4;
-const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4" };
+constexpr int kNumVariants = 6;
+const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s" };
 
-int pick_variant(int flags, size_t n_tris) {
+int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_samples) {
 	const int v = flags & SPHIP_KERNEL_MASK;
 	if (v >= 1 && v <= kNumVariants) return v;
-	return n_tris >= 64 ? 3 : 1;      // tiny scenes: nothing to filter, the scalar path has no barriers
+	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
+	// Path tracing with >= 2 spp: two consecutive SAMPLES of a pixel per lane (rpl_filter2s).  It halves the LDS reads
+	// per test like two pixels per lane do, keeps 256 pixels per workgroup so that small shards (8-GPU row tiles of
+	// a 1080p frame: 1020 workgroups) still fill the 256 CUs x 4 workgroup slots, and measured fastest at every
+	// shard size (profiles/r01_shard_speed.log).  One scan per ray (flat pass, 1 spp): two pixels per lane when
+	// that still leaves >= ~768 workgroups, else one.
+	if (mode == SPHIP_MODE_PT && n_samples >= 2) return 6;
+	return n_rays >= 384u * 1024u ? 3 : 5;
 }
 
 int repack(sphip_ctx* c, hipStream_t st) {
@@ -131,12 +138,12 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	}
 	a.inv_n = (float)(1.0 / (double)(n_samples ? n_samples : 1));      // cpu_renderer.cpp:77
 
-	const int variant = pick_variant(flags, c->n_tris);
+	const int variant = pick_variant(flags, c->n_tris, n_rays, mode, n_samples);
 	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, 8 * sizeof(unsigned long long), st));
 	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
 	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
 	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray
-	const uint32_t n_work = (uint32_t)((n_rays + 1023) / 1024 * 1024);
+	const uint32_t n_work = (uint32_t)((n_rays + 1023) / 1024 * 1024) * (variant == 6 ? 2u : 1u);
 	int2* hist = nullptr; float* acc = nullptr;
 	if (mode == SPHIP_MODE_PT && variant >= 3) {
 		if ((rc = ensure(c, c->work, (size_t)n_work * 52))) return rc;
@@ -148,18 +155,22 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
 	if (mode == kModeHits) {
 		int* oi = (int*)d_rgba; float* od = (float*)d_accum;
-		if (variant == 4)      hipLaunchKernelGGL(sp::k_hit_filter<4>, grid4, block, 0, st, a, filt, bnd, d_src, oi, od);
+		if (variant >= 5)      hipLaunchKernelGGL(sp::k_hit_filter<1>, grid, block, 0, st, a, filt, bnd, d_src, oi, od);
+		else if (variant == 4) hipLaunchKernelGGL(sp::k_hit_filter<4>, grid4, block, 0, st, a, filt, bnd, d_src, oi, od);
 		else if (variant == 3) hipLaunchKernelGGL(sp::k_hit_filter<2>, grid2, block, 0, st, a, filt, bnd, d_src, oi, od);
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_hit<2>, grid, block, 0, st, a, d_src, oi, od);
 		else                   hipLaunchKernelGGL(sp::k_hit<1>, grid, block, 0, st, a, d_src, oi, od);
 	} else if (mode == SPHIP_MODE_FLAT) {
-		if (variant == 4)      hipLaunchKernelGGL(sp::k_flat_filter<4>, grid4, block, 0, st, a, filt, bnd);
+		if (variant >= 5)      hipLaunchKernelGGL(sp::k_flat_filter<1>, grid, block, 0, st, a, filt, bnd);
+		else if (variant == 4) hipLaunchKernelGGL(sp::k_flat_filter<4>, grid4, block, 0, st, a, filt, bnd);
 		else if (variant == 3) hipLaunchKernelGGL(sp::k_flat_filter<2>, grid2, block, 0, st, a, filt, bnd);
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_flat<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
 	} else {
-		if (variant == 4)      hipLaunchKernelGGL(sp::k_pt_filter<4>, grid4, block, 0, st, a, filt, bnd, hist, acc, n_work);
-		else if (variant == 3) hipLaunchKernelGGL(sp::k_pt_filter<2>, grid2, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		if (variant == 6)      hipLaunchKernelGGL((sp::k_pt_filter<2, true>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		else if (variant == 5) hipLaunchKernelGGL((sp::k_pt_filter<1, false>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		else if (variant == 4) hipLaunchKernelGGL((sp::k_pt_filter<4, false>), grid4, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		else if (variant == 3) hipLaunchKernelGGL((sp::k_pt_filter<2, false>), grid2, block, 0, st, a, filt, bnd, hist, acc, n_work);
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_pt<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
 	}
