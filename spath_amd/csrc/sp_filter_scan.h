@@ -34,7 +34,6 @@
 
 namespace sp {
 
-constexpr uint32_t kU = 4;  // triangles per filter-loop iteration (one branch per kU x R tests)
 constexpr int kQCap = 24;   // queue entries per lane (u16: slot<<8 | index in tile); 12 KB, keeps 4 workgroups per CU
 
 // filter record: 48 B = 3 x float4, produced by k_repack_filter
@@ -141,6 +140,7 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 	const uint32_t n_tris = a.n_tris;
 	const uint32_t ntiles = (n_tris + kTile - 1) / kTile;
 
+	constexpr uint32_t kU = R >= 4 ? 2u : 4u;   // triangles per filter-loop iteration: one branch per kU x R (= 8) tests
 	f3 P[R];
 	float Dq[R];
 #pragma unroll
@@ -227,10 +227,18 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 					const uint32_t ent = qs[e * 256 + tid];
 					const int slot = (int)(ent >> 8);
 					const uint32_t idx = base + (ent & 0xffu);
-					f3 o = s.o[0], dir = s.dir[0];
+					// pick the slot's ray with explicit per-component selects (a struct copy under `if (slot == r)` made the
+					// compiler index the slot array dynamically and spill it to scratch for R = 4)
+					float ox = s.o[0].x, oy = s.o[0].y, oz = s.o[0].z, dx = s.dir[0].x, dy = s.dir[0].y, dz = s.dir[0].z;
 					int src = s.src[0];
 #pragma unroll
-					for (int r = 1; r < R; ++r) if (slot == r) { o = s.o[r]; dir = s.dir[r]; src = s.src[r]; }
+					for (int r = 1; r < R; ++r) {
+						const bool pick = (slot == r);
+						ox = pick ? s.o[r].x : ox; oy = pick ? s.o[r].y : oy; oz = pick ? s.o[r].z : oz;
+						dx = pick ? s.dir[r].x : dx; dy = pick ? s.dir[r].y : dy; dz = pick ? s.dir[r].z : dz;
+						src = pick ? s.src[r] : src;
+					}
+					const f3 o = mk3(ox, oy, oz), dir = mk3(dx, dy, dz);
 					const float4 x0 = a.scan[3 * idx + 0], x1 = a.scan[3 * idx + 1], x2 = a.scan[3 * idx + 2];
 					const float d = ray_tri_strict(o, dir, mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
 #pragma unroll

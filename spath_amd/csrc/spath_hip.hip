@@ -68,8 +68,8 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 	return SPHIP_OK;
 }
 
-constexpr int kNumVariants = 6;
-const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s" };
+constexpr int kNumVariants = 7;
+const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s" };
 
 int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_samples) {
 	const int v = flags & SPHIP_KERNEL_MASK;
@@ -143,7 +143,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
 	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
 	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray
-	const uint32_t n_work = (uint32_t)((n_rays + 1023) / 1024 * 1024) * (variant == 6 ? 2u : 1u);
+	const uint32_t n_work = (uint32_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u);
 	int2* hist = nullptr; float* acc = nullptr;
 	if (mode == SPHIP_MODE_PT && variant >= 3) {
 		if ((rc = ensure(c, c->work, (size_t)n_work * 52))) return rc;
@@ -167,7 +167,8 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_flat<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
 	} else {
-		if (variant == 6)      hipLaunchKernelGGL((sp::k_pt_filter<2, true>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		if (variant == 7)      hipLaunchKernelGGL((sp::k_pt_filter<4, true>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		else if (variant == 6) hipLaunchKernelGGL((sp::k_pt_filter<2, true>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
 		else if (variant == 5) hipLaunchKernelGGL((sp::k_pt_filter<1, false>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
 		else if (variant == 4) hipLaunchKernelGGL((sp::k_pt_filter<4, false>), grid4, block, 0, st, a, filt, bnd, hist, acc, n_work);
 		else if (variant == 3) hipLaunchKernelGGL((sp::k_pt_filter<2, false>), grid2, block, 0, st, a, filt, bnd, hist, acc, n_work);

@@ -19,7 +19,7 @@ from spath_amd.dist import RowTilePlan, ShardedRenderer
 pytestmark = pytest.mark.gpu
 
 ACCUM_LINF_TOLERANCE = 0.0          # float accumulators: exact
-VARIANTS = [1, 2, 3, 4, 5, 6]       # rpl_sload, rpl_lds, rpl_filter2, rpl_filter4, rpl_filter1, rpl_filter2s
+VARIANTS = [1, 2, 3, 4, 5, 6, 7]    # rpl_sload, rpl_lds, rpl_filter2, rpl_filter4, rpl_filter1, rpl_filter2s, rpl_filter4s
 
 
 def dev(a):
