@@ -103,6 +103,25 @@ int sphip_render_device(sphip_t* ctx, const void* d_rays /* n_rays*6 f32: the sh
                         void* d_out_rgba /* n_rays*4 u8 */, void* d_out_accum /* n_rays*3 f32 or NULL */,
                         void* stream);
 
+/* ---- device-side viewport generation (camera -> rays without the 24 B/pixel upload).
+ * Same arithmetic as view::camera::get_viewport (src/view.h:94-132), float operation for float operation, so the
+ * rays are bit-identical to what renderer::get_viewport hands to render().  The camera's trigonometric values are
+ * computed by the caller exactly like the reference does on the host (src/view.h:77-80,87-92: std::cos/std::sin of
+ * angle.y and angle.x) and passed in. */
+typedef struct {
+	float pos[3];                 /* view::camera::pos   (src/view.h:70) */
+	float cos_y, sin_y, cos_x, sin_x;
+	float focal;                  /* view::camera::focal (src/view.h:72) */
+	uint32_t res_x, res_y;
+} sphip_camera;
+
+int sphip_viewport_device(sphip_t* ctx, const sphip_camera* cam, void* d_rays_out /* res_x*res_y*6 f32 */, void* stream);
+
+/* get_viewport + render / render_flat in one call, rays never leave the device: equals
+ * sphip_render(ctx, rays_of(cam), cam->res_x, cam->res_y, ...).  Blocking; host output pointers. */
+int sphip_render_camera(sphip_t* ctx, const sphip_camera* cam, size_t n_samples, uint64_t seed, int mode, int flags,
+                        uint8_t* out_rgba, float* out_accum);
+
 /* The closest-hit scan on its own (the loop of src/cpu_renderer.cpp:36-49 for each ray): for ray k writes the
  * index of the nearest accepted triangle (or -1) and its distance d (MAX_VALUE_DIST = 1e12f on a miss).
  * d_src_idx (may be NULL) gives each ray's idx_source, the triangle to skip (:40-41); NULL means -1 for all.

@@ -20,12 +20,24 @@ FLAG_PRIMARY_REUSE = 0x100
 SYMBOLS = (
     "sphip_create", "sphip_destroy", "sphip_last_error", "sphip_description", "sphip_abi_version",
     "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
-    "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats",
+    "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats", "sphip_viewport_device", "sphip_render_camera",
 )
 
 
 class Shard(C.Structure):
     _fields_ = [("pixel_base", C.c_uint64), ("tile_px", C.c_uint64), ("tile_stride_px", C.c_uint64)]
+
+
+class CameraArgs(C.Structure):
+    """sphip_camera: view::camera state with the trig values the reference computes on the host (view.h:77-80)."""
+    _fields_ = [("pos", C.c_float * 3), ("cos_y", C.c_float), ("sin_y", C.c_float), ("cos_x", C.c_float), ("sin_x", C.c_float),
+                ("focal", C.c_float), ("res_x", C.c_uint32), ("res_y", C.c_uint32)]
+
+    @classmethod
+    def from_camera(cls, cam):
+        """cam: spath_amd.view.Camera"""
+        return cls((C.c_float * 3)(*[float(x) for x in cam.pos]), float(cam.cosY), float(cam.sinY), float(cam.cosX), float(cam.sinX),
+                   float(cam.focal), int(cam.res_x), int(cam.res_y))
 
 
 class Stats(C.Structure):
@@ -75,6 +87,10 @@ def load():
     L.sphip_render_device.argtypes = [vp, vp, sz, C.POINTER(Shard), sz, sz, C.c_uint64, C.c_int, C.c_int, vp, vp, vp]
     L.sphip_closest_hit_device.restype = C.c_int
     L.sphip_closest_hit_device.argtypes = [vp, vp, sz, vp, C.c_int, vp, vp, vp]
+    L.sphip_viewport_device.restype = C.c_int
+    L.sphip_viewport_device.argtypes = [vp, C.POINTER(CameraArgs), vp, vp]
+    L.sphip_render_camera.restype = C.c_int
+    L.sphip_render_camera.argtypes = [vp, C.POINTER(CameraArgs), sz, C.c_uint64, C.c_int, C.c_int, vp, vp]
     L.sphip_get_stats.restype = C.c_int
     L.sphip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     _lib = L
@@ -161,6 +177,22 @@ class Context:
                            flags=0, stream: int = 0):
         self._check(self._L.sphip_closest_hit_device(self._h, d_rays, n_rays, d_src_idx or None, flags,
                                                      d_out_idx, d_out_dist, stream or None), "sphip_closest_hit_device")
+
+    def viewport_device(self, cam, d_rays_out: int, stream: int = 0):
+        """camera::get_viewport on the device (cam: spath_amd.view.Camera); writes res_x*res_y*6 floats."""
+        ca = CameraArgs.from_camera(cam)
+        self._check(self._L.sphip_viewport_device(self._h, C.byref(ca), d_rays_out, stream or None), "sphip_viewport_device")
+
+    def render_camera(self, cam, n_samples, seed=1, mode=MODE_PT, flags=0, want_accum=False):
+        """get_viewport + render in one call; the rays never leave the device."""
+        import numpy as np
+        ca = CameraArgs.from_camera(cam)
+        n = cam.res_x * cam.res_y
+        out = np.zeros((n, 4), dtype=np.uint8)
+        acc = np.zeros((n, 3), dtype=np.float32) if want_accum else None
+        self._check(self._L.sphip_render_camera(self._h, C.byref(ca), n_samples, seed, mode, flags, out.ctypes.data,
+                                                acc.ctypes.data if want_accum else None), "sphip_render_camera")
+        return (out, acc) if want_accum else out
 
     def stats(self) -> dict:
         s = Stats()

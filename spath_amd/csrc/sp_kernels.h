@@ -45,6 +45,33 @@ __global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, 
 	scan[(size_t)i * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
 }
 
+// ---- view::camera::get_viewport (view.h:94-132) on the device: one thread per pixel.
+// The eight step constants are computed on the host in the reference's mixed double/float way (view.h:101-108).
+struct ViewArgs {
+	float x_max, x_step, h_x_step, y_max, y_step, h_y_step;
+	float focal, cos_y, sin_y, cos_x, sin_x;
+	float px, py, pz;
+	uint32_t res_x, res_y;
+};
+
+SP_DEV f3 cam_rel_move(const ViewArgs& v, f3 in) {                               // view.h:83-85 = rY(rX(in))
+	const f3 a = mk3(in.x, in.y * v.cos_x + in.z * -v.sin_x, in.y * v.sin_x + in.z * v.cos_x);   // :62-68
+	return mk3(a.x * v.cos_y + a.z * v.sin_y, a.y, a.x * -v.sin_y + a.z * v.cos_y);              // :54-60
+}
+
+__global__ void __launch_bounds__(256) k_viewport(const ViewArgs v, float* __restrict__ rays) {
+	const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+	if (idx >= v.res_x * v.res_y) return;
+	const int i = (int)(idx % v.res_x), j = (int)(idx / v.res_x);                 // :112 index = i + j*res_x
+	const f3 cur = mk3(v.x_max - v.x_step * (float)i - v.h_x_step, v.y_max - v.y_step * (float)j - v.h_y_step, 0.0f);   // :111
+	const f3 t = add3(cur, mk3(0.0f, 0.0f, v.focal));                             // :114
+	const float l = __builtin_sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);           // geom.h:130-136 (IEEE sqrt)
+	const f3 dir = cam_rel_move(v, mk3(t.x / l, t.y / l, t.z / l));               // :138-141 then view.h:127
+	const f3 pos = add3(cam_rel_move(v, cur), mk3(v.px, v.py, v.pz));             // view.h:126,131
+	float* o = rays + (size_t)idx * 6;
+	o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = dir.x; o[4] = dir.y; o[5] = dir.z;
+}
+
 SP_DEV uint64_t shard_pixel(const KArgs& a, uint32_t k) {
 	const uint64_t t = (uint64_t)k / a.tile_px;
 	return a.pixel_base + t * a.tile_stride_px + ((uint64_t)k - t * a.tile_px);

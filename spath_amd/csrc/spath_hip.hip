@@ -281,6 +281,56 @@ int sphip_render_device(sphip_t* c, const void* d_rays, size_t n_rays, const sph
 	return launch_render(c, d_rays, n_rays, shard, image_width, n_samples, seed, mode, flags, d_out_rgba, d_out_accum, (hipStream_t)stream);
 }
 
+static int launch_viewport(sphip_ctx* c, const sphip_camera* cam, void* d_rays, hipStream_t st) {
+	if (!cam || !d_rays) return fail(c, SPHIP_E_INVALID, "null camera or ray pointer");
+	if (cam->res_x == 0 || cam->res_y == 0 || (uint64_t)cam->res_x * cam->res_y > 0xffffffffull)
+		return fail(c, SPHIP_E_INVALID, "bad viewport size %ux%u", cam->res_x, cam->res_y);
+	sp::ViewArgs v{};
+	// view.h:101-108: `real` (float) variables initialised from double expressions
+	const float x_size = (float)(1.0 * (double)cam->res_x / (double)cam->res_y), y_size = 1.0f;
+	v.x_max = (float)((double)x_size / 2.0);
+	v.x_step = x_size / (float)cam->res_x;
+	v.h_x_step = (float)((double)v.x_step / 2.0);
+	v.y_max = (float)((double)y_size / 2.0);
+	v.y_step = y_size / (float)cam->res_y;
+	v.h_y_step = (float)((double)v.y_step / 2.0);
+	v.focal = cam->focal; v.cos_y = cam->cos_y; v.sin_y = cam->sin_y; v.cos_x = cam->cos_x; v.sin_x = cam->sin_x;
+	v.px = cam->pos[0]; v.py = cam->pos[1]; v.pz = cam->pos[2];
+	v.res_x = cam->res_x; v.res_y = cam->res_y;
+	const uint32_t n = cam->res_x * cam->res_y;
+	hipLaunchKernelGGL(sp::k_viewport, dim3((n + 255) / 256), dim3(256), 0, st, v, (float*)d_rays);
+	HIP_TRY(c, hipGetLastError());
+	return SPHIP_OK;
+}
+
+int sphip_viewport_device(sphip_t* c, const sphip_camera* cam, void* d_rays_out, void* stream) {
+	if (!c) return SPHIP_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	return launch_viewport(c, cam, d_rays_out, (hipStream_t)stream);
+}
+
+int sphip_render_camera(sphip_t* c, const sphip_camera* cam, size_t n_samples, uint64_t seed, int mode, int flags,
+                        uint8_t* out_rgba, float* out_accum) {
+	if (!c) return SPHIP_E_INVALID;
+	if (!cam || !out_rgba) return fail(c, SPHIP_E_INVALID, "null camera or output pointer");
+	HIP_TRY(c, hipSetDevice(c->device));
+	const size_t n = (size_t)cam->res_x * cam->res_y;
+	hipStream_t st = c->own_stream;
+	int rc;
+	if ((rc = ensure(c, c->rays, (n ? n : 1) * 24)) || (rc = ensure(c, c->rgba, (n ? n : 1) * 4))) return rc;
+	if (out_accum && (rc = ensure(c, c->accum, n * 12))) return rc;
+	if ((rc = launch_viewport(c, cam, c->rays.p, st))) return rc;
+	if ((rc = launch_render(c, c->rays.p, n, nullptr, cam->res_x, n_samples, seed, mode, flags, c->rgba.p, out_accum ? c->accum.p : nullptr, st))) return rc;
+	HIP_TRY(c, hipEventRecord(c->ev_d0, st));
+	HIP_TRY(c, hipMemcpyAsync(out_rgba, c->rgba.p, n * 4, hipMemcpyDeviceToHost, st));
+	if (out_accum) HIP_TRY(c, hipMemcpyAsync(out_accum, c->accum.p, n * 12, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipEventRecord(c->ev_d1, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	c->timed_upload = false;
+	c->timed_download = true;
+	return SPHIP_OK;
+}
+
 int sphip_closest_hit_device(sphip_t* c, const void* d_rays, size_t n_rays, const void* d_src_idx, int flags,
                              void* d_out_idx, void* d_out_dist, void* stream) {
 	if (!c) return SPHIP_E_INVALID;

@@ -9,6 +9,7 @@
 
 #include "spath_hip.h"
 
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -51,14 +52,41 @@ struct hip_r : public basic_renderer {
 		return h;
 	}
 
-	void frame(const view::viewport& vp, const geom::triangle* tris, const scene::material* mats, const size_t n_tris,
-	           const size_t n_samples, scene::bitmap& out, const int mode) {
+	void upload_scene(const geom::triangle* tris, const scene::material* mats, const size_t n_tris) {
 		unsigned long long h = fnv(tris, n_tris * sizeof(geom::triangle), 1469598103934665603ull);
 		h = fnv(mats, n_tris * sizeof(scene::material), h);
 		if (h != scene_hash || n_tris != scene_n) {
 			check(sphip_set_scene(ctx, (const float*)tris, (const float*)mats, n_tris), "set_scene");
 			scene_hash = h; scene_n = n_tris;
 		}
+	}
+
+	// the camera as the C ABI wants it; the trig values are recomputed with the same float std::cos/std::sin calls the
+	// reference's camera makes (src/view.h:77-80,87-92) -- its cached copies are private
+	sphip_camera camera_args() const {
+		sphip_camera c;
+		c.pos[0] = vc.pos.x; c.pos[1] = vc.pos.y; c.pos[2] = vc.pos.z;
+		c.cos_y = std::cos(vc.angle.y); c.sin_y = std::sin(vc.angle.y);
+		c.cos_x = std::cos(vc.angle.x); c.sin_x = std::sin(vc.angle.x);
+		c.focal = vc.focal;
+		c.res_x = (uint32_t)vc.res_x; c.res_y = (uint32_t)vc.res_y;
+		return c;
+	}
+
+	void frame_own_viewport(const geom::triangle* tris, const scene::material* mats, const size_t n_tris, const size_t n_samples,
+	                        scene::bitmap& out, const int mode) {
+		upload_scene(tris, mats, n_tris);
+		out.res_x = vc.res_x;
+		out.res_y = vc.res_y;
+		out.values.resize(out.res_x * out.res_y);
+		const sphip_camera c = camera_args();
+		check(sphip_render_camera(ctx, &c, n_samples, seed, mode, flags, (uint8_t*)out.values.data(), 0), "render_camera");
+		have_stats = sphip_get_stats(ctx, &stats) == SPHIP_OK;
+	}
+
+	void frame(const view::viewport& vp, const geom::triangle* tris, const scene::material* mats, const size_t n_tris,
+	           const size_t n_samples, scene::bitmap& out, const int mode) {
+		upload_scene(tris, mats, n_tris);
 		// first ensure that the bitmap is of correct size (src/cpu_renderer.cpp:120-122)
 		out.res_x = vp.res_x;
 		out.res_y = vp.res_y;
@@ -91,6 +119,14 @@ namespace hip_renderer {
 
 	void set_flags(scene::renderer* r, int flags) {
 		if (hip_r* p = dynamic_cast<hip_r*>(r)) p->flags = flags;
+	}
+
+	bool render_own_viewport(scene::renderer* r, const geom::triangle* tris, const scene::material* mats, const size_t n_tris,
+	                         const size_t n_samples, scene::bitmap& out, const bool flat) {
+		hip_r* p = dynamic_cast<hip_r*>(r);
+		if (!p) return false;
+		p->frame_own_viewport(tris, mats, n_tris, n_samples ? n_samples : 1, out, flat ? SPHIP_MODE_FLAT : SPHIP_MODE_PT);
+		return true;
 	}
 
 	bool last_stats(scene::renderer* r, double* kernel_ms, unsigned long long* scans) {

@@ -14,6 +14,10 @@ namespace hip_renderer {
 	// frames and the C-ABI flags word (kernel variant, primary-hit reuse; see include/spath_hip.h).
 	extern void set_seed(scene::renderer* r, unsigned long long seed);
 	extern void set_flags(scene::renderer* r, int flags);
+	// get_viewport + render (or render_flat) with the viewport generated on the device from the renderer's own
+	// camera (bit-identical rays, no 24 B/pixel upload).  Returns false if r is not a hip renderer.
+	extern bool render_own_viewport(scene::renderer* r, const geom::triangle* tris, const scene::material* mats, const size_t n_tris,
+	                                const size_t n_samples, scene::bitmap& out, const bool flat);
 	// kernel milliseconds and closest-hit scans of the last frame (0 if r is not a hip renderer)
 	extern bool last_stats(scene::renderer* r, double* kernel_ms, unsigned long long* scans);
 }

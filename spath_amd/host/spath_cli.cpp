@@ -5,6 +5,7 @@
 //
 //   spath_cli [--scene default|FILE.bin] [--w 640 --h 480] [--spp 128] [--mode pt|flat]
 //             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--out image.ppm|image.rgba] [--frames n]
+//             [--device-viewport]
 #include "hip_renderer.h"
 
 #include <chrono>
@@ -64,6 +65,7 @@ bool load_scene(const char* path, std::vector<geom::triangle>& t, std::vector<sc
 int main(int argc, char** argv) {
 	try {
 		std::string scene_arg = "default", mode = "pt", out_path;
+		bool device_viewport = false;
 		int w = 640, h = 480, frames = 1, flags = 0;                 // window default of the reference (main.cpp:238-239)
 		size_t spp = 128;                                            // main.cpp:44
 		unsigned long long seed = 1;
@@ -80,6 +82,7 @@ int main(int argc, char** argv) {
 			else if (k == "--flags") { need(1); flags = std::atoi(argv[++i]); }
 			else if (k == "--frames") { need(1); frames = std::atoi(argv[++i]); }
 			else if (k == "--out") { need(1); out_path = argv[++i]; }
+			else if (k == "--device-viewport") device_viewport = true;
 			else if (k == "--mov" || k == "--rot") { need(3); moves.push_back(std::make_pair(k[2], geom::vec3(std::atof(argv[i + 1]), std::atof(argv[i + 2]), std::atof(argv[i + 3])))); i += 3; }
 			else if (k == "--focal") { need(1); moves.push_back(std::make_pair('f', geom::vec3(std::atof(argv[++i]), 0, 0))); }
 			else throw std::runtime_error("unknown argument " + k);
@@ -102,9 +105,13 @@ int main(int argc, char** argv) {
 		scene::bitmap bmp;
 		for (int f = 0; f < frames; ++f) {
 			const auto t0 = std::chrono::steady_clock::now();
-			r->get_viewport(vp);                                         // main.cpp:74
-			if (mode == "pt") r->render(vp, tris.data(), mats.data(), tris.size(), spp, bmp);
-			else r->render_flat(vp, tris.data(), mats.data(), tris.size(), spp, bmp);
+			if (device_viewport) {                                       // rays generated on the GPU, never uploaded
+				hip_renderer::render_own_viewport(r.get(), tris.data(), mats.data(), tris.size(), spp, bmp, mode != "pt");
+			} else {
+				r->get_viewport(vp);                                     // main.cpp:74
+				if (mode == "pt") r->render(vp, tris.data(), mats.data(), tris.size(), spp, bmp);
+				else r->render_flat(vp, tris.data(), mats.data(), tris.size(), spp, bmp);
+			}
 			const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 			double kms = 0; unsigned long long scans = 0;
 			hip_renderer::last_stats(r.get(), &kms, &scans);

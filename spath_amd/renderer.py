@@ -103,6 +103,15 @@ class HipRenderer(BasicRenderer):
     def render(self, vp, tris, mats, n_tris, n_samples, out):
         self._render(vp, tris, mats, n_tris, n_samples, out, capi.MODE_PT)
 
+    def render_own_viewport(self, tris, mats, n_tris, n_samples, out: Bitmap, flat: bool = False):
+        """get_viewport + render(_flat) without moving rays over PCIe: the viewport is generated on the device
+        from this renderer's own camera (bit-identical to get_viewport)."""
+        self._upload_scene(tris, mats, n_tris)
+        out.res_x, out.res_y = self.vc.res_x, self.vc.res_y
+        out.values = self.ctx.render_camera(self.vc, max(int(n_samples), 1), seed=self.seed,
+                                            mode=capi.MODE_FLAT if flat else capi.MODE_PT, flags=self.flags)
+        self.last_stats = self.ctx.stats()
+
     def close(self):
         self.ctx.close()
 

@@ -315,3 +315,28 @@ def test_config2_default_720p_against_oracle(hip, O, scenes):
     want_img, want_acc, scans = O.render_counter(rays, t, m, spp, 1)
     assert np.abs(acc - want_acc).max() <= ACCUM_LINF_TOLERANCE
     assert np.array_equal(img, want_img) and st["scans_executed"] == scans
+
+
+def test_device_side_viewport_is_bit_identical(hip, O):
+    """SURVEY 8(f2): camera::get_viewport (view.h:94-132) on the device == the reference's rays, and
+    render_camera == render(get_viewport())."""
+    moves_sets = [(), (("mov", (0.3, 0.1, -0.5)), ("rot", (0.1, -0.25, 0.0)), ("focal", 0.5)), (("rot", (0.0, 1.0, 0.0)), ("mov", (0.0, 0.0, 1.0)))]
+    for (w, h) in [(320, 240), (64, 48), (7, 5), (1, 1), (1920, 1080), (333, 17)]:
+        for moves in moves_sets:
+            cam = view.Camera(w, h)
+            for k, v in moves:
+                {"mov": cam.set_delta_mov, "rot": cam.set_delta_rot, "focal": cam.set_delta_focal}[k](v)
+            want = cam.get_viewport()                     # python mirror; equals the oracle / reference for these cameras
+            d = torch.zeros(w * h, 6, dtype=torch.float32, device="cuda")
+            hip.viewport_device(cam, d.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), want.view(np.uint32)), (w, h, moves)
+    assert np.array_equal(view.Camera(320, 240).get_viewport().view(np.uint32), O.viewport(320, 240).view(np.uint32))
+    t, m = scene.default_scene()
+    hip.set_scene(t, m)
+    cam = view.Camera(96, 64)
+    cam.set_delta_mov((0.2, 0.0, -0.3)); cam.set_delta_rot((0.0, 0.2, 0.0))
+    a, aacc = hip.render(cam.get_viewport(), 96, 64, 5, seed=3, want_accum=True)
+    b, bacc = hip.render_camera(cam, 5, seed=3, want_accum=True)
+    assert np.array_equal(a, b) and np.array_equal(aacc, bacc)
+    assert np.array_equal(hip.render_camera(cam, 1, mode=capi.MODE_FLAT), hip.render(cam.get_viewport(), 96, 64, 1, mode=capi.MODE_FLAT))

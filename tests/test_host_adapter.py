@@ -45,6 +45,9 @@ def test_cli_images_equal_oracle(tmp_path, O):
         p = subprocess.run([CLI, "--w", str(w), "--h", str(h), "--spp", "5", "--seed", "77", "--out", out] + moves, check=True, capture_output=True, text=True)
         assert "Current renderer: HIP - Path Tracing" in p.stdout and "Done (" in p.stdout
         assert np.array_equal(np.fromfile(out, dtype=np.uint8).reshape(-1, 4), O.render_counter(rays, t, m, 5, 77)[0])
+        # viewport generated on the device from the adapter's camera (C++ float std::cos/std::sin for the trig values)
+        subprocess.run([CLI, "--w", str(w), "--h", str(h), "--spp", "5", "--seed", "77", "--device-viewport", "--out", out] + moves, check=True, capture_output=True)
+        assert np.array_equal(np.fromfile(out, dtype=np.uint8).reshape(-1, 4), O.render_counter(rays, t, m, 5, 77)[0])
     # scene file + PPM output
     sp = os.path.join(tmp_path, "s.bin")
     ts, ms = scene.closed_room(300)
