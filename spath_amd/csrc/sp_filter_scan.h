@@ -34,7 +34,13 @@
 
 namespace sp {
 
-constexpr int kQCap = 24;   // queue entries per lane (u16: slot<<8 | index in tile); 12 KB, keeps 4 workgroups per CU
+#ifndef SP_FLUSH_TILES
+#define SP_FLUSH_TILES 1   /* measured: 2 gives +0.8 %, 4 overflows the 24-entry queues (profiles/r01_flush_batching.log) */
+#endif
+constexpr uint32_t kFlushTiles = SP_FLUSH_TILES;   // tiles between two exact stages
+constexpr uint32_t kIdxBits = 10;      // queue entry: slot << kIdxBits | triangle index within the epoch (< kFlushTiles*kTile)
+static_assert(kFlushTiles * 256u <= (1u << kIdxBits), "queue index bits");
+constexpr int kQCap = 24;   // queue entries per lane (u16); 12 KB, keeps 4 workgroups per CU
 
 // filter record: 48 B = 3 x float4, produced by k_repack_filter
 //   q0 = w.x w.y w.z M0.x   q1 = M0.y M0.z M1.x M1.y   q2 = M1.z 0 0 0
@@ -162,6 +168,8 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 	__syncthreads();                            // readers of the previous scan are done with sm
 	tile_dma(filt, sm, tid, wbase);
 	__syncthreads();                            // (the barrier's fence waits for the DMA: vmcnt(0))
+	uint32_t qn = 0;                              // survivors queued by this lane since the last flush (may exceed kQCap: overflow)
+	uint32_t epoch = 0;                           // first tile of the current flush epoch
 	for (uint32_t t = 0; t < ntiles; ++t) {
 		const float4* cur = sm + (t & 1u) * kTileQ;
 		const uint32_t left = n_tris - t * kTile;
@@ -169,8 +177,7 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		// groups of kU triangles; a ragged tail reads padding records (w = M = 0: they survive stage 1 and are
 		// then rejected by the exact stage, whose padding record has a = 0)
 		const uint32_t qend = ((cnt + kU - 1u) / kU) * (3u * kU);
-		const uint32_t base = t * kTile;
-		uint32_t qn = 0;                          // survivors of this lane in this tile (may exceed kQCap: overflow)
+		const uint32_t tile_off = (t - epoch) * kTile;   // index of this tile's first triangle relative to the epoch base
 		for (uint32_t q = 0; q < qend; q += 3u * kU) {      // q: float4 offset of the group, wave-uniform (scalar loop)
 			float4 a0[kU], a1[kU];
 			float a2[kU];
@@ -197,7 +204,7 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 #pragma unroll
 					for (int r = 0; r < R; ++r) if (sv[u][r]) {
 						const uint32_t e = qn < (uint32_t)kQCap ? qn : (uint32_t)kQCap - 1u;
-						qs[e * 256 + tid] = (unsigned short)((r << 8) | (j0 + u));
+						qs[e * 256 + tid] = (unsigned short)((r << kIdxBits) | (tile_off + j0 + u));
 						++qn;
 					}
 			}
@@ -205,50 +212,58 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		// the next tile streams in while the survivors are processed (issued here, not before the filter loop:
 		// the compiler orders every LDS read behind an outstanding LDS-DMA with s_waitcnt vmcnt(0))
 		if (t + 1 < ntiles) tile_dma(filt + (size_t)(t + 1) * kTileQ, sm + ((t + 1) & 1u) * kTileQ, tid, wbase);
+		// ---- stage 2: exact tests of the survivors queued since the last flush, in queue (= index) order.
+		// Flushing every kFlushTiles tiles instead of every tile makes the rounds fuller: a round costs the same
+		// whatever the number of lanes that still have an entry, and max-over-lanes of a sum grows slower than the sum.
+		if (t + 1 - epoch == kFlushTiles || t + 1 == ntiles) {
 #ifdef SP_FILTER_STATS
 		{   // experiment build only: survivors, exact rounds, tiles per wave -> a.scans[1..3]
 			uint32_t v = qn, mx = qn;
 			for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); const uint32_t o2 = __shfl_xor(mx, off, 64); mx = o2 > mx ? o2 : mx; }
-			if ((tid & 63u) == 0) { atomicAdd(a.scans + 1, (unsigned long long)v); atomicAdd(a.scans + 2, (unsigned long long)mx); atomicAdd(a.scans + 3, 1ull); }
+			if ((tid & 63u) == 0) { atomicAdd(a.scans + 1, (unsigned long long)v); atomicAdd(a.scans + 2, (unsigned long long)mx); atomicAdd(a.scans + 3, 1ull); if (mx > (uint32_t)kQCap) atomicAdd(a.scans + 4, 1ull); }
 		}
 #endif
 #ifdef SP_ABLATE_NOFLUSH
 		if (qn == 0x0fffffffu) bi[0] = 1;         // timing experiment only (wrong images): keep qn alive, skip the exact stage
 		qn = 0;
 #endif
-		// ---- stage 2: exact tests of this tile's survivors, in queue (= index) order
-		if (__builtin_expect(__any(qn > (uint32_t)kQCap), 0)) {
-			// some lane overflowed its queue: the whole wave re-scans the tile exactly (rare: scenes made of
-			// triangles so large that most rays cross their slabs)
-			exact_range<R>(a.scan, base, base + cnt, s, bd, bi);
-		} else {
-			for (uint32_t e = 0; __any(e < qn); ++e) {
-				if (e < qn) {
-					const uint32_t ent = qs[e * 256 + tid];
-					const int slot = (int)(ent >> 8);
-					const uint32_t idx = base + (ent & 0xffu);
-					// pick the slot's ray with explicit per-component selects (a struct copy under `if (slot == r)` made the
-					// compiler index the slot array dynamically and spill it to scratch for R = 4)
-					float ox = s.o[0].x, oy = s.o[0].y, oz = s.o[0].z, dx = s.dir[0].x, dy = s.dir[0].y, dz = s.dir[0].z;
-					int src = s.src[0];
+			const uint32_t base = epoch * kTile;
+			if (__builtin_expect(__any(qn > (uint32_t)kQCap), 0)) {
+				// some lane overflowed its queue: the whole wave re-scans the epoch exactly (rare: scenes made of
+				// triangles so large that most rays cross their slabs)
+				const uint32_t hi = (t + 1) * kTile;
+				exact_range<R>(a.scan, base, hi < n_tris ? hi : n_tris, s, bd, bi);
+			} else {
+				for (uint32_t e = 0; __any(e < qn); ++e) {
+					if (e < qn) {
+						const uint32_t ent = qs[e * 256 + tid];
+						const int slot = (int)(ent >> kIdxBits);
+						const uint32_t idx = base + (ent & ((1u << kIdxBits) - 1u));
+						// pick the slot's ray with explicit per-component selects (a struct copy under `if (slot == r)` made the
+						// compiler index the slot array dynamically and spill it to scratch for R = 4)
+						float ox = s.o[0].x, oy = s.o[0].y, oz = s.o[0].z, dx = s.dir[0].x, dy = s.dir[0].y, dz = s.dir[0].z;
+						int src = s.src[0];
 #pragma unroll
-					for (int r = 1; r < R; ++r) {
-						const bool pick = (slot == r);
-						ox = pick ? s.o[r].x : ox; oy = pick ? s.o[r].y : oy; oz = pick ? s.o[r].z : oz;
-						dx = pick ? s.dir[r].x : dx; dy = pick ? s.dir[r].y : dy; dz = pick ? s.dir[r].z : dz;
-						src = pick ? s.src[r] : src;
-					}
-					const f3 o = mk3(ox, oy, oz), dir = mk3(dx, dy, dz);
-					const float4 x0 = a.scan[3 * idx + 0], x1 = a.scan[3 * idx + 1], x2 = a.scan[3 * idx + 2];
-					const float d = ray_tri_strict(o, dir, mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+						for (int r = 1; r < R; ++r) {
+							const bool pick = (slot == r);
+							ox = pick ? s.o[r].x : ox; oy = pick ? s.o[r].y : oy; oz = pick ? s.o[r].z : oz;
+							dx = pick ? s.dir[r].x : dx; dy = pick ? s.dir[r].y : dy; dz = pick ? s.dir[r].z : dz;
+							src = pick ? s.src[r] : src;
+						}
+						const f3 o = mk3(ox, oy, oz), dir = mk3(dx, dy, dz);
+						const float4 x0 = a.scan[3 * idx + 0], x1 = a.scan[3 * idx + 1], x2 = a.scan[3 * idx + 2];
+						const float d = ray_tri_strict(o, dir, mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
 #pragma unroll
-					for (int r = 0; r < R; ++r) {
-						const bool take = (slot == r) && (d > 0.0f) && (d < bd[r]) && ((int)idx != src);
-						bd[r] = take ? d : bd[r];
-						bi[r] = take ? (int)idx : bi[r];
+						for (int r = 0; r < R; ++r) {
+							const bool take = (slot == r) && (d > 0.0f) && (d < bd[r]) && ((int)idx != src);
+							bd[r] = take ? d : bd[r];
+							bi[r] = take ? (int)idx : bi[r];
+						}
 					}
 				}
 			}
+			qn = 0;
+			epoch = t + 1;
 		}
 		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
 	}

@@ -379,10 +379,10 @@ int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 	c->stats.scans_executed = scans;
 #ifdef SP_FILTER_STATS
 	{
-		unsigned long long x[4] = {0, 0, 0, 0};
+		unsigned long long x[5] = {0, 0, 0, 0, 0};
 		(void)hipMemcpy(x, c->counter.p, sizeof x, hipMemcpyDeviceToHost);
-		fprintf(stderr, "[filter stats] survivors=%llu rounds(sum of per-wave max)=%llu wave_tiles=%llu -> survivors/lane/tile=%.3f rounds/tile=%.2f\n",
-		        x[1], x[2], x[3], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3]);
+		fprintf(stderr, "[filter stats] survivors=%llu rounds(sum of per-wave max)=%llu wave_flushes=%llu overflows=%llu -> survivors/lane/flush=%.3f rounds/flush=%.2f\n",
+		        x[1], x[2], x[3], x[4], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3]);
 	}
 #endif
 	*out = c->stats;

@@ -1,0 +1,124 @@
+"""Inputs far outside the comfortable range: the conservative filter must degrade to 'keep' (never to a wrong
+reject), so every scan kernel still agrees bit for bit with the oracle's strict evaluation."""
+import numpy as np
+import pytest
+import torch
+
+from spath_amd import capi, scene, view
+
+pytestmark = pytest.mark.gpu
+VARIANTS = [1, 2, 3, 5, 6]
+
+
+def _hits(hip, O, t, rays, tag):
+    n = rays.shape[0]
+    want_idx, want_d = O.closest_hits(rays, t)
+    d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
+    d_idx = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_d = torch.zeros(n, dtype=torch.float32, device="cuda")
+    for v in VARIANTS:
+        hip.closest_hit_device(d_rays.data_ptr(), n, d_idx.data_ptr(), d_d.data_ptr(), flags=v)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_idx.cpu().numpy(), want_idx), (tag, v)
+        assert np.array_equal(d_d.cpu().numpy().view(np.uint32), want_d.view(np.uint32)), (tag, v)
+    return want_idx
+
+
+def _rays(rng, n, scale, center):
+    o = rng.uniform(-1.4, 1.4, (n, 3)) * [1, 0.5, 1]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o * scale + center, d], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("scale,shift", [(1.0, 0.0), (1e-4, 0.0), (1e4, 0.0), (1.0, 3e4), (1e-3, 5e2), (1e12, 0.0), (1e20, 0.0)])
+def test_scaled_and_shifted_scenes(hip, O, scale, shift):
+    """The same closed room scaled by 1e-4 .. 1e20 and pushed 3e4 units from the origin (large cancellation in the
+    ray moment): at 1e20 the filter's products overflow to inf/NaN and every pair must fall through to the exact test."""
+    t, m = scene.closed_room(700)
+    t = t.copy()
+    t[:, :9] = (t[:, :9].astype(np.float64) * scale + shift).astype(np.float32)
+    hip.set_scene(t, m)
+    rays = _rays(np.random.default_rng(4), 3000, scale, shift)
+    idx = _hits(hip, O, t, rays, (scale, shift))
+    if scale <= 1e4:                     # beyond ~1e11 the distances exceed MAX_VALUE_DIST = 1e12 and the reference itself reports misses
+        assert (idx >= 0).mean() > 0.9
+
+
+def test_nonfinite_and_degenerate_inputs(hip, O):
+    t, m = scene.closed_room(300)
+    t = t.copy()
+    t[20, 0] = np.inf
+    t[21, 4] = np.nan
+    t[22, :9] = 0.0                      # a point
+    t[23, 3:6] = t[23, 0:3]              # a segment
+    hip.set_scene(t, m)
+    rng = np.random.default_rng(9)
+    rays = _rays(rng, 2000, 1.0, 0.0)
+    rays[5, 3:] = 0.0                    # zero direction
+    rays[6, 0] = np.nan
+    rays[7, 4] = np.inf
+    rays[8, 3:] *= 1e-30
+    rays[9, 3:] *= 1e30
+    _hits(hip, O, t, rays, "nonfinite")
+    # and a full render of that scene still equals the oracle
+    w, h = 48, 36
+    vp = view.Camera(w, h).get_viewport()
+    want = O.render_counter(vp, t, m, 3, 2)
+    for v in VARIANTS:
+        img, acc = hip.render(vp, w, h, 3, seed=2, flags=v, want_accum=True)
+        assert np.array_equal(img, want[0]), v
+        assert np.array_equal(acc, want[1], equal_nan=True), v
+
+
+def test_many_samples_and_odd_counts(hip, O, scenes):
+    """Sample-split lanes: odd sample counts, one sample, more samples than a byte."""
+    t, m = scenes["default"]
+    rays = view.Camera(23, 17).get_viewport()
+    hip.set_scene(t, m)
+    for spp in (1, 2, 3, 255, 257):
+        want = O.render_counter(rays, t, m, spp, 11)
+        for v in (6, 7):
+            img, acc = hip.render(rays, 23, 17, spp, seed=11, flags=v, want_accum=True)
+            assert np.array_equal(img, want[0]) and np.array_equal(acc, want[1]), (spp, v)
+            assert hip.stats()["scans_executed"] == want[2]
+
+
+def test_fuzz_filter_scan_against_exact_scan(hip):
+    """Bulk fuzz on the GPU alone: random triangle soups (sizes over five decades, slivers, clustered and
+    spread) x random rays; the two-stage scans must return exactly what the exact LDS scan returns.
+    About 2.4e9 ray-triangle pairs per kernel variant."""
+    rng = np.random.default_rng(2026)
+    for it in range(30):
+        n = int(rng.integers(65, 3000))
+        size = 10.0 ** rng.uniform(-3, 1.5)
+        spread = 10.0 ** rng.uniform(-1, 2)
+        ctr = rng.normal(size=(n, 1, 3)) * spread
+        v = ctr + rng.normal(size=(n, 3, 3)) * size * (10.0 ** rng.uniform(-2, 0, size=(n, 1, 1)))
+        if it % 3 == 0:                               # slivers: third vertex almost on the first edge
+            v[:, 2] = v[:, 0] + (v[:, 1] - v[:, 0]) * rng.uniform(0, 1, (n, 1)) + rng.normal(size=(n, 3)) * size * 1e-4
+        t = np.zeros((n, 12), dtype=np.float32)
+        t[:, :9] = v.reshape(n, 9)
+        t = scene.flat_normals(t)
+        m = np.ones((n, 6), dtype=np.float32)
+        hip.set_scene(t, m)
+        nr = 40000
+        o = rng.normal(size=(nr, 3)) * spread * 1.5
+        # aim at random interior/edge/vertex points of random triangles, half of them jittered off the triangle
+        bc = rng.dirichlet([0.5, 0.5, 0.5], nr)
+        tri = v[rng.integers(0, n, nr)]
+        tgt = (tri * bc[:, :, None]).sum(axis=1) + rng.normal(size=(nr, 3)) * size * 0.3 * (rng.random((nr, 1)) < 0.5)
+        d = tgt - o
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+        rays = np.concatenate([o, d], axis=1).astype(np.float32)
+        src = rng.integers(-1, n, nr).astype(np.int32)
+        d_rays, d_src = torch.from_numpy(rays).cuda(), torch.from_numpy(src).cuda()
+        res = {}
+        for var in (2, 3, 5):
+            di = torch.zeros(nr, dtype=torch.int32, device="cuda"); dd = torch.zeros(nr, dtype=torch.float32, device="cuda")
+            hip.closest_hit_device(d_rays.data_ptr(), nr, di.data_ptr(), dd.data_ptr(), d_src_idx=d_src.data_ptr(), flags=var)
+            torch.cuda.synchronize()
+            res[var] = (di.cpu().numpy(), dd.cpu().numpy().view(np.uint32))
+        for var in (3, 5):
+            assert np.array_equal(res[var][0], res[2][0]) and np.array_equal(res[var][1], res[2][1]), (it, var, n, size, spread)
+        assert (res[2][0] >= 0).mean() > 0.02, (it, n, size, spread)     # the rays do hit things

@@ -12,7 +12,7 @@ rays = view.Camera(1920, 1080).get_viewport()
 for world in (8, 1):
     plan = RowTilePlan(1920, 1080, world, 8)
     sh = ShardedRenderer(ctx, plan, 0, rays, torch.device("cuda"))
-    for var in (6, 7):
+    for var in (6,):
         for rep in range(2):
             sh.render(8, flags=var); torch.cuda.synchronize(); st = ctx.stats()
         print(f"world {world}: shard {sh.n} px, variant {var}->{st['kernel_variant']}: {st['kernel_ms']:.1f} ms, {st['scans_executed']*1e4/st['kernel_ms']/1e9:.3f} T tests/s", flush=True)
