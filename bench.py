@@ -65,8 +65,14 @@ def cpu_baseline(tris, mats, args):
     cores = host_cores()
     w, h, spp = args.cpu_w, args.cpu_h, args.cpu_spp
     nominal = w * h * spp * 5
+    info = None
     if O.have_ref():
-        _, info = O.ref_run("render", w, h, spp, tris, mats, threads=cores, return_info=True)
+        try:
+            _, info = O.ref_run("render", w, h, spp, tris, mats, threads=cores, return_info=True)
+        except Exception as e:                 # e.g. the prebuilt binary does not run on this host: time the port instead
+            print(f"bench.py: oracle/_ref/spath_ref failed ({e}); timing the C restatement", file=sys.stderr)
+            info = None
+    if info and "seconds" in info:
         secs, kind = info["seconds"], "reference"
         what = "unmodified reference cpu_renderer (oracle/_ref/spath_ref)"
     else:

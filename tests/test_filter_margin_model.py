@@ -1,0 +1,134 @@
+"""CPU-side check of the two-stage scan's error model, independent of the GPU.
+
+For random and adversarial (ray, triangle) pairs it evaluates, in float32 numpy with the reference's operation
+order, the quantities the strict test computes (a_f, sh_f = s.h, vq_f = dir.q) and, with an emulated float32
+FMA chain, the filter's g0, g1 for each of the three slabs, and checks
+  1. the measured discrepancy |g0*|base| - strict value| stays far below the bound D = 36u |dir| (|pos|+|v0|+|v1|)
+     the derivation allows (44u for the third slab), and
+  2. the filter decision  |med3(g0, g1, 0)| > Dq  never fires on a pair the strict test accepts.
+"""
+import numpy as np
+
+F = np.float32
+U = 2.0 ** -24
+
+
+def fma(a, b, c):
+    # float32 fused multiply-add emulated through float64 (the product of two floats is exact in double)
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+
+
+def cross(a, b):
+    return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], axis=1)
+
+
+def dot(a, b):
+    return (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]
+
+
+def strict(pos, d, v0, v1, v2):
+    """geom::ray_intersect (geom.h:197-222) in float32, returning the accept mask and the intermediates."""
+    e1, e2 = v1 - v0, v2 - v0
+    h = cross(d, e2)
+    a = dot(e1, h)
+    with np.errstate(all="ignore"):
+        f = (1.0 / a.astype(np.float64)).astype(F)
+        s = pos - v0
+        sh = dot(s, h)
+        u = f * sh
+        q = cross(s, e1)
+        vq = dot(d, q)
+        v = f * vq
+        dist = f * dot(e2, q)
+    eps = F(1e-14)
+    acc = ~((a > -eps) & (a < eps)) & ~((u < 0) | (u > 1)) & ~((v < 0) | ((u + v) > 1)) & (dist > eps) & (dist.astype(np.float64) < 1.0 / float(eps))
+    return acc, a, sh, vq, e1, e2
+
+
+def filter_g(pos, d, w, p0, p1):
+    """k_repack_filter + slab_survives arithmetic: records rounded to float32, g by an FMA chain."""
+    wn = (w / np.linalg.norm(w, axis=1, keepdims=True)).astype(F)
+    wd = wn.astype(np.float64)
+    M0 = np.cross(wd, p0.astype(np.float64)).astype(F)
+    M1 = np.cross(wd, p1.astype(np.float64)).astype(F)
+    P = cross(pos, d)
+    A = wn[:, 0] * P[:, 0]
+    A = fma(wn[:, 1], P[:, 1], A)
+    A = fma(wn[:, 2], P[:, 2], A)
+    g = []
+    for M in (M0, M1):
+        x = fma(-d[:, 0], M[:, 0], A)
+        x = fma(-d[:, 1], M[:, 1], x)
+        x = fma(-d[:, 2], M[:, 2], x)
+        g.append(x)
+    return g[0], g[1]
+
+
+def make_pairs(rng, n):
+    scale = 10.0 ** rng.uniform(-2, 1, (n, 1))
+    ctr = rng.normal(size=(n, 3)) * 3
+    v = [(ctr + rng.normal(size=(n, 3)) * scale).astype(F) for _ in range(3)]
+    bc = rng.dirichlet([0.4, 0.4, 0.4], n)
+    tgt = v[0] * bc[:, :1] + v[1] * bc[:, 1:2] + v[2] * bc[:, 2:3]
+    tgt = tgt + rng.normal(size=(n, 3)) * scale * 0.2 * (rng.random((n, 1)) < 0.5)
+    pos = (rng.normal(size=(n, 3)) * 4).astype(F)
+    d = tgt - pos
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+    return pos, d, v[0], v[1], v[2]
+
+
+def test_error_model_and_conservativeness():
+    rng = np.random.default_rng(77)
+    n = 400_000
+    pos, d, v0, v1, v2 = make_pairs(rng, n)
+    acc, a, sh, vq, e1, e2 = strict(pos, d, v0, v1, v2)
+    assert acc.mean() > 0.2                                    # plenty of accepted pairs, many on edges/vertices
+    nd = np.linalg.norm(d.astype(np.float64), axis=1)
+    mag = nd * (np.linalg.norm(pos.astype(np.float64), axis=1) + np.linalg.norm(v0.astype(np.float64), axis=1)
+                + np.linalg.norm(v1.astype(np.float64), axis=1) + np.linalg.norm(v2.astype(np.float64), axis=1))
+    d1 = np.abs(d).sum(axis=1).astype(np.float64)
+    p1n = np.abs(pos).sum(axis=1).astype(np.float64)
+    rv = max(np.abs(x).sum(axis=1).max() for x in (v0, v1, v2))
+    Dq = 2.0 ** -16 * 1.01 * d1 * (p1n + 2.0 * rv)
+    c = (e2.astype(np.float64) - e1.astype(np.float64))
+    slabs = {
+        "u": (e2, v0, v1, sh.astype(np.float64), (a.astype(np.float64) - sh.astype(np.float64)), 36.0),
+        "v": (e1, v0, v2, -vq.astype(np.float64), -(a.astype(np.float64) - vq.astype(np.float64)), 37.0),   # v*a = -(pos-v0).(dir x e1)
+        "w": (c.astype(F), v1, v0, None, None, 44.0),
+    }
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    l1, l2, lc = (e1d ** 2).sum(1), (e2d ** 2).sum(1), (c ** 2).sum(1)
+    chosen = np.where((l2 >= l1) & (l2 >= lc), "u", np.where(l1 >= lc, "v", "w"))      # k_repack_filter's rule: the longest edge
+    seen = 0
+    for name, (w, p0, p1, x0, x1, bound_u) in slabs.items():
+        g0, g1 = filter_g(pos, d, w.astype(F), p0, p1)
+        base = np.linalg.norm(w.astype(np.float64), axis=1)
+        if name == "w":
+            X = sh.astype(np.float64) + vq.astype(np.float64)          # sh + dir.q = s.(dir x c) = (pos-v0).(dir x c)
+            # the filter uses p0 = v1: (pos-v1).(dir x c) = X - a ; p1 = v0: X
+            x0, x1 = X - a.astype(np.float64), -X
+        ok = np.isfinite(g0) & np.isfinite(g1) & (base > 0) & (chosen == name)       # each slab is only ever used on its own triangles
+        seen += int(ok.sum())
+        r0 = np.abs(g0[ok].astype(np.float64) * base[ok] - x0[ok]) / (U * base[ok] * mag[ok])
+        r1 = np.abs((-g1[ok]).astype(np.float64) * base[ok] - x1[ok]) / (U * base[ok] * mag[ok])
+        assert r0.max() < bound_u and r1.max() < bound_u, (name, r0.max(), r1.max())
+        assert max(r0.max(), r1.max()) < 12.0, (name, r0.max(), r1.max())     # in practice an order of magnitude below the bound
+        med = np.where((g0 > 0) & (g1 > 0), np.minimum(g0, g1), np.where((g0 < 0) & (g1 < 0), np.maximum(g0, g1), F(0)))
+        reject = np.abs(med.astype(np.float64)) > Dq
+        assert not (reject & acc & ok).any(), (name, int((reject & acc & ok).sum()))
+        assert reject[ok].mean() > 0.1                                        # and it does reject
+        print(f"slab {name}: {int(ok.sum())} pairs, max discrepancy {max(r0.max(), r1.max()):.2f} u (bound {bound_u:.0f} u), "
+              f"rejects {reject[ok].mean():.3f}, accepted by the strict test {acc[ok].mean():.3f}")
+    assert seen == n
+
+
+def test_longest_edge_choice_matches_kernel_rule():
+    """k_repack_filter: ties go to e2, then e1 (l2 >= l1 && l2 >= lc; else l1 >= lc)."""
+    rng = np.random.default_rng(3)
+    v0, v1, v2 = (rng.normal(size=(1000, 3)).astype(F) for _ in range(3))
+    e1, e2 = (v1 - v0).astype(np.float64), (v2 - v0).astype(np.float64)
+    c = e2 - e1
+    l1, l2, lc = (e1 ** 2).sum(1), (e2 ** 2).sum(1), (c ** 2).sum(1)
+    pick = np.where((l2 >= l1) & (l2 >= lc), 2, np.where(l1 >= lc, 1, 3))
+    longest = np.maximum(np.maximum(l1, l2), lc)
+    assert np.array_equal(np.where(pick == 2, l2, np.where(pick == 1, l1, lc)), longest)
