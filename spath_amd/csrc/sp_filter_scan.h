@@ -32,6 +32,10 @@
 
 #include "sp_kernels.h"
 
+#ifndef SP_PT_WAVES
+#define SP_PT_WAVES 4      // occupancy target (waves per SIMD) of the path-trace kernel: 4 workgroups of 36 KB LDS per CU
+#endif
+
 namespace sp {
 
 #ifndef SP_FLUSH_TILES
