@@ -44,7 +44,10 @@ namespace sp {
 constexpr uint32_t kFlushTiles = SP_FLUSH_TILES;   // tiles between two exact stages
 constexpr uint32_t kIdxBits = 10;      // queue entry: slot << kIdxBits | triangle index within the epoch (< kFlushTiles*kTile)
 static_assert(kFlushTiles * 256u <= (1u << kIdxBits), "queue index bits");
-constexpr int kQCap = 24;   // queue entries per lane (u16); 12 KB, keeps 4 workgroups per CU
+#ifndef SP_QCAP
+#define SP_QCAP 24
+#endif
+constexpr int kQCap = SP_QCAP;   // queue entries per lane (u16); 12 KB, keeps 4 workgroups per CU
 
 // filter record: 48 B = 3 x float4, produced by k_repack_filter
 //   q0 = w.x w.y w.z M0.x   q1 = M0.y M0.z M1.x M1.y   q2 = M1.z 0 0 0
