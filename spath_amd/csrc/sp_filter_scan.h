@@ -55,10 +55,14 @@ __global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__
                                                       unsigned int* __restrict__ bounds, uint32_t n, uint32_t n_padded) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_padded) return;
-	if (i >= n) {   // padding: w = M = 0 -> g0 = g1 = 0 -> survivor; never queued because the loop stops at n rounded up to 4,
-		            // and the exact stage rejects the zero exact record (a = 0)
-		const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		filt[(size_t)i * 3 + 0] = z; filt[(size_t)i * 3 + 1] = z; filt[(size_t)i * 3 + 2] = z;
+	if (i >= n) {
+		// padding behind the last triangle (the filter loop reads whole groups of 2-4 records): w = 0, M0 = M1 = (H,H,H)
+		// gives g0 = g1 = -H (dx+dy+dz), same sign and huge, i.e. rejected unless dx+dy+dz is ~0; a padding record that
+		// does survive meets a zero exact record (a = 0) in stage 2 and is rejected there
+		const float H = 1e30f;
+		filt[(size_t)i * 3 + 0] = make_float4(0.0f, 0.0f, 0.0f, H);
+		filt[(size_t)i * 3 + 1] = make_float4(H, H, H, H);
+		filt[(size_t)i * 3 + 2] = make_float4(H, 0.0f, 0.0f, 0.0f);
 		return;
 	}
 	const float* t = tris + (size_t)i * 12;
@@ -181,8 +185,8 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		const float4* cur = sm + (t & 1u) * kTileQ;
 		const uint32_t left = n_tris - t * kTile;
 		const uint32_t cnt = left < (uint32_t)kTile ? left : (uint32_t)kTile;
-		// groups of kU triangles; a ragged tail reads padding records (w = M = 0: they survive stage 1 and are
-		// then rejected by the exact stage, whose padding record has a = 0)
+		// groups of kU triangles; a ragged tail reads padding records (see k_repack_filter: rejected by stage 1,
+		// or failing that by stage 2)
 		const uint32_t qend = ((cnt + kU - 1u) / kU) * (3u * kU);
 		const uint32_t tile_off = (t - epoch) * kTile;   // index of this tile's first triangle relative to the epoch base
 		for (uint32_t q = 0; q < qend; q += 3u * kU) {      // q: float4 offset of the group, wave-uniform (scalar loop)
