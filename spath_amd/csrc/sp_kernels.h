@@ -99,9 +99,8 @@ SP_DEV void scan_rpl_sload(const float4* __restrict__ scan, uint32_t n_tris, f3 
 // ---- closest-hit scan, variant "rpl_lds": ray per lane; the workgroup streams the scan records
 // HBM/L2 -> registers -> LDS in coalesced 16-byte pieces (double-buffered tiles of kTile triangles),
 // and every lane reads the current triangle from LDS at a wave-uniform address (hardware broadcast),
-// so all VALU operands are VGPRs (SGPR operands run at ~63 % of the VGPR rate on gfx950, see
-// profiles/r01_first_contact_parity_and_valu_microbench.log).  One triangle fetched from L2/HBM is
-// shared by the 256 rays of the workgroup.  Must be called by every thread of the block.
+// so all VALU operands are VGPRs.  One triangle fetched from L2/HBM is shared by the 256 rays of the
+// workgroup.  Must be called by every thread of the block.
 constexpr int kTile = 256;                      // triangles per LDS tile (12 KB), two tiles in flight
 constexpr int kTileQ = kTile * 3;               // float4 per tile
 static_assert(kTileQ % 256 == 0, "tile must split evenly over the 256 threads");
