@@ -143,7 +143,10 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
 	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
 	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray
-	const uint32_t n_work = (uint32_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u);
+	const uint64_t n_work64 = (uint64_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u);
+	if (mode == SPHIP_MODE_PT && variant >= 3 && n_work64 > 0xffffffffull)
+		return fail(c, SPHIP_E_INVALID, "n_rays %zu too large for one launch of this kernel variant; shard the frame", n_rays);
+	const uint32_t n_work = (uint32_t)n_work64;
 	int2* hist = nullptr; float* acc = nullptr;
 	if (mode == SPHIP_MODE_PT && variant >= 3) {
 		if ((rc = ensure(c, c->work, (size_t)n_work * 52))) return rc;
