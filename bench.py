@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--kernel", type=str, default="auto", help="scan kernel variant (see sphip_kernel_name)")
     ap.add_argument("--primary-reuse", action="store_true", help="scan the primary ray once per pixel (fewer scans; off for roofline runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-reference", action="store_true", help="skip the untimed exact-only scan reference run")
     ap.add_argument("--cpu-w", type=int, default=192)
     ap.add_argument("--cpu-h", type=int, default=108)
     ap.add_argument("--cpu-spp", type=int, default=16)
@@ -181,6 +182,20 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ctx.stats()                       # figures of the last launch on this rank
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    # outside the timed region, for reference: the exact-only scan (every pair through the full Moeller-Trumbore test,
+    # no conservative pre-test) on the same frame at 8 spp -- same image bits, ~4x the instructions per test
+    exact_only = None
+    if world == 1 and NT >= 64 and not args.no_exact_reference:
+        spp_x = min(SPP, 8)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        shard.render(spp_x, seed=1, mode=capi.MODE_PT, flags=variants["rpl_lds"], stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        sx = ctx.stats()
+        exact_only = {"kernel": "rpl_lds", "spp": spp_x, "kernel_ms": round(e0.elapsed_time(e1), 3),
+                      "Mray_per_s": round(W * H * spp_x * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2),
+                      "tests_per_s": round(sx["scans_executed"] * NT / (e0.elapsed_time(e1) * 1e-3), 1)}
     if world > 1:
         cdev = torch.device("cpu") if rehearsal else dev
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -236,6 +251,7 @@ def main():
             # per-channel sums of the assembled RGBA8 frame: identical for every --gpus N (pixel-keyed RNG)
             "image_sum_rgb": [int(x) for x in image[:, :3].to(torch.int64).sum(dim=0).tolist()],
             "nominal_rays_per_step": nominal,
+            "exact_scan_only": exact_only,
             "roofline": {
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
