@@ -95,7 +95,9 @@ int sphip_render(sphip_t* ctx, const float* rays, size_t w, size_t h, size_t n_s
 /* ---- device-resident path: pointers are HIP device pointers on ctx's device, `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing; outputs are complete
  * when the stream reaches the end of the enqueued work.  Used for HBM-resident benchmarking and for
- * pixel-row-tile sharding across GPUs (one context per GPU). */
+ * pixel-row-tile sharding across GPUs (one context per GPU).  Stream order is the only ordering: issue
+ * sphip_set_scene_device and the renders that use that scene on the same stream (or synchronise in between);
+ * d_tris / d_mats are copied, so they may be freed once the stream has passed the call. */
 int sphip_set_scene_device(sphip_t* ctx, const void* d_tris, const void* d_mats, size_t n_tris, void* stream);
 int sphip_render_device(sphip_t* ctx, const void* d_rays /* n_rays*6 f32: the shard's rays */, size_t n_rays,
                         const sphip_shard* shard /* NULL = {0, n_rays, 0} */, size_t image_width,
