@@ -207,6 +207,13 @@ def main():
         exact_only["with_primary_reuse"] = {"spp": spp_r, "kernel_ms": round(e0.elapsed_time(e1), 3),
                                             "nominal_Mray_per_s": round(W * H * spp_r * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2),
                                             "scans_executed": sr["scans_executed"], "nominal_scans": W * H * spp_r * 5}
+        # and the OPT-IN acceleration structure (linear BVH): a different work definition, never the headline
+        e0.record()
+        shard.render(spp_r, seed=1, mode=capi.MODE_PT, flags=capi.FLAG_ACCEL, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        exact_only["with_accel_structure_opt_in"] = {"spp": spp_r, "kernel_ms": round(e0.elapsed_time(e1), 3),
+                                                     "nominal_Mray_per_s": round(W * H * spp_r * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2)}
     if world > 1:
         cdev = torch.device("cpu") if rehearsal else dev
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)

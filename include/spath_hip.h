@@ -49,8 +49,13 @@ enum {
 	SPHIP_KERNEL_AUTO = 0,          /* let the library pick the scan kernel */
 	SPHIP_KERNEL_MASK = 0xff,       /* low byte: explicit kernel variant (see sphip_kernel_name) for A/B runs;
 	                                   every variant produces bit-identical images */
-	SPHIP_FLAG_PRIMARY_REUSE = 0x100 /* scan the (identical) primary ray of a pixel once for all its samples
+	SPHIP_FLAG_PRIMARY_REUSE = 0x100,/* scan the (identical) primary ray of a pixel once for all its samples
 	                                   (src/cpu_renderer.cpp:74-76 re-scans it); identical image, fewer scans */
+	SPHIP_FLAG_ACCEL = 0x200         /* OPT-IN acceleration structure (linear BVH).  Changes the work
+	                                   definition: the reference tests every triangle (README.md:23).  Same strict triangle
+	                                   test and tie rule, so every geometric hit is reproduced bit for bit; what it cannot
+	                                   reproduce are the reference's rounding-noise accepts on rays almost coplanar with a
+	                                   far-away triangle.  Never used by bench.py's headline figure. */
 };
 
 /* Pixel-shard descriptor: which global pixel the k-th ray of a shard is.

@@ -15,6 +15,7 @@ MODE_FLAT = 0
 MODE_PT = 1
 KERNEL_AUTO = 0
 FLAG_PRIMARY_REUSE = 0x100
+FLAG_ACCEL = 0x200          # opt-in linear BVH; not the brute-force path
 
 # every entry point include/spath_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (

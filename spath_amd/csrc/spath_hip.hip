@@ -7,13 +7,17 @@
 #include "spath_hip.h"
 #include "sp_kernels.h"
 #include "sp_filter_scan.h"
+#include "sp_bvh.h"
 
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -30,7 +34,9 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter, work;
+	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx;
+	bool bvh_valid = false;
+	uint32_t bvh_leaves = 0;
 	size_t n_tris = 0;
 	bool have_scene = false;
 	bool have_render = false, timed_upload = false, timed_download = false;
@@ -68,10 +74,13 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 	return SPHIP_OK;
 }
 
-constexpr int kNumVariants = 7;
-const char* const kVariantNames[kNumVariants + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s" };
+constexpr int kNumVariants = 7;       // selectable brute-force scan kernels; 8 = the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
+constexpr int kVariantAccel = 8;
+const char* const kVariantNames[kVariantAccel + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
+                                                      "accel_lbvh" };
 
 int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_samples) {
+	if (flags & SPHIP_FLAG_ACCEL) return kVariantAccel;
 	const int v = flags & SPHIP_KERNEL_MASK;
 	if (v >= 1 && v <= kNumVariants) return v;
 	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
@@ -99,6 +108,82 @@ int repack(sphip_ctx* c, hipStream_t st) {
 	                   (const float*)c->tris.p, (float4*)c->filt.p, (unsigned int*)c->bounds.p, n, n_pad);
 	HIP_TRY(c, hipGetLastError());
 	c->have_scene = true;
+	c->bvh_valid = false;
+	return SPHIP_OK;
+}
+
+// ---- linear BVH for SPHIP_FLAG_ACCEL (sp_bvh.h), built on the host the first time a scene is rendered with the flag
+uint32_t morton10(float x) {   // x in [0,1): spread 10 bits to every third position
+	uint32_t v = (uint32_t)std::min(std::max(x * 1024.0f, 0.0f), 1023.0f);
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+
+int ensure_bvh(sphip_ctx* c, hipStream_t st) {
+	if (c->bvh_valid) return SPHIP_OK;
+	const size_t n = c->n_tris;
+	std::vector<float> t(n * 12);
+	HIP_TRY(c, hipMemcpyAsync(t.data(), c->tris.p, n * 48, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	// scene box and Morton order of the centroids
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (size_t i = 0; i < n; ++i)
+		for (int k = 0; k < 9; ++k) { const float v = t[i * 12 + k]; if (std::isfinite(v)) { lo[k % 3] = std::min(lo[k % 3], v); hi[k % 3] = std::max(hi[k % 3], v); } }
+	float ext[3], scale = 0.0f;
+	for (int a = 0; a < 3; ++a) { if (!(hi[a] >= lo[a])) { lo[a] = 0; hi[a] = 0; } ext[a] = hi[a] - lo[a]; scale = std::max(scale, std::max(std::fabs(lo[a]), std::fabs(hi[a]))); }
+	std::vector<std::pair<uint32_t, uint32_t>> order(n);
+	for (size_t i = 0; i < n; ++i) {
+		uint32_t code = 0;
+		for (int a = 0; a < 3; ++a) {
+			const float cen = (t[i * 12 + a] + t[i * 12 + 3 + a] + t[i * 12 + 6 + a]) * (1.0f / 3.0f);
+			const float u = ext[a] > 0 ? (cen - lo[a]) / ext[a] : 0.0f;
+			code |= morton10(std::isfinite(u) ? u : 0.0f) << a;
+		}
+		order[i] = { code, (uint32_t)i };
+	}
+	std::sort(order.begin(), order.end());
+	const uint32_t l0 = (uint32_t)((n + 3) / 4);
+	uint32_t nl = 1;
+	while (nl < l0) nl <<= 1;
+	std::vector<float> nodes((size_t)2 * nl * 8), rec((size_t)nl * 4 * 12, 0.0f);
+	std::vector<int> idx((size_t)nl * 4, -1);
+	auto box = [&](uint32_t node) { return &nodes[(size_t)node * 8]; };   // lo.xyz hi.x | hi.yz pad pad
+	for (uint32_t node = 0; node < 2 * nl; ++node) { float* b = box(node); b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY; b[6] = b[7] = 0; }
+	for (size_t j = 0; j < n; ++j) {
+		const uint32_t i = order[j].second;
+		const float* s = &t[(size_t)i * 12];
+		float* r = &rec[j * 12];
+		r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
+		r[3] = s[3] - s[0]; r[4] = s[4] - s[1]; r[5] = s[5] - s[2];      // e1, e2: the reference's float subtractions (geom.h:200-201)
+		r[6] = s[6] - s[0]; r[7] = s[7] - s[1]; r[8] = s[8] - s[2];
+		idx[j] = (int)i;
+		float* b = box(nl + (uint32_t)(j / 4));
+		for (int k = 0; k < 9; ++k) { const float v = s[k]; if (std::isfinite(v)) { b[k % 3] = std::min(b[k % 3], v); b[3 + k % 3] = std::max(b[3 + k % 3], v); } }
+	}
+	// inflate the leaves (the slab test runs in float: keep every geometric hit inside), then refit bottom-up
+	for (uint32_t leaf = nl; leaf < 2 * nl; ++leaf) {
+		float* b = box(leaf);
+		if (!(b[3] >= b[0])) continue;                    // empty (padding) leaf: inverted box, never entered
+		for (int a = 0; a < 3; ++a) {
+			const float pad = 1e-5f * std::max(std::max(std::fabs(b[a]), std::fabs(b[3 + a])), b[3 + a] - b[a]) + 1e-6f * scale + 1e-30f;
+			b[a] -= pad; b[3 + a] += pad;
+		}
+	}
+	for (uint32_t node = nl - 1; node >= 1; --node) {
+		float* b = box(node); const float* l = box(2 * node); const float* r = box(2 * node + 1);
+		for (int a = 0; a < 3; ++a) { b[a] = std::min(l[a], r[a]); b[3 + a] = std::max(l[3 + a], r[3 + a]); }
+	}
+	int rc;
+	if ((rc = ensure(c, c->bvh_nodes, nodes.size() * 4)) || (rc = ensure(c, c->bvh_rec, rec.size() * 4)) || (rc = ensure(c, c->bvh_idx, idx.size() * 4))) return rc;
+	HIP_TRY(c, hipMemcpyAsync(c->bvh_nodes.p, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(c->bvh_rec.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(c->bvh_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipStreamSynchronize(st));          // the staging vectors die with this call
+	c->bvh_leaves = nl;
+	c->bvh_valid = true;
 	return SPHIP_OK;
 }
 
@@ -155,8 +240,18 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	}
 	const float4* filt = (const float4*)c->filt.p;
 	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
+	sp::BvhArgs B{};
+	if (variant == kVariantAccel) {
+		if ((rc = ensure_bvh(c, st))) return rc;
+		B.nodes = (const float4*)c->bvh_nodes.p; B.leaf_rec = (const float4*)c->bvh_rec.p; B.leaf_idx = (const int*)c->bvh_idx.p;
+		B.n_leaves = c->bvh_leaves; B.first_leaf = c->bvh_leaves;
+	}
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
-	if (mode == kModeHits) {
+	if (variant == kVariantAccel) {
+		if (mode == kModeHits)           hipLaunchKernelGGL(sp::k_accel<2>, grid, block, 0, st, a, B, d_src, (int*)d_rgba, (float*)d_accum);
+		else if (mode == SPHIP_MODE_FLAT) hipLaunchKernelGGL(sp::k_accel<0>, grid, block, 0, st, a, B, nullptr, nullptr, nullptr);
+		else                              hipLaunchKernelGGL(sp::k_accel<1>, grid, block, 0, st, a, B, nullptr, nullptr, nullptr);
+	} else if (mode == kModeHits) {
 		int* oi = (int*)d_rgba; float* od = (float*)d_accum;
 		if (variant >= 5)      hipLaunchKernelGGL(sp::k_hit_filter<1>, grid, block, 0, st, a, filt, bnd, d_src, oi, od);
 		else if (variant == 4) hipLaunchKernelGGL(sp::k_hit_filter<4>, grid4, block, 0, st, a, filt, bnd, d_src, oi, od);
@@ -196,7 +291,7 @@ extern "C" {
 int sphip_abi_version(void) { return SPHIP_ABI_VERSION; }
 
 const char* sphip_kernel_name(int variant) {
-	if (variant < 0 || variant > kNumVariants) return nullptr;
+	if (variant < 0 || variant > kVariantAccel) return nullptr;
 	return kVariantNames[variant];
 }
 
@@ -237,7 +332,8 @@ void sphip_destroy(sphip_t* c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[10] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work };
+	DevBuf* bufs[13] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -380,6 +476,13 @@ int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 	HIP_TRY(c, hipMemcpyAsync(&scans, c->counter.p, sizeof scans, hipMemcpyDeviceToHost, c->last_stream));
 	HIP_TRY(c, hipStreamSynchronize(c->last_stream));
 	c->stats.scans_executed = scans;
+#ifdef SP_BVH_STATS
+	{
+		unsigned long long x[3] = {0, 0, 0};
+		(void)hipMemcpy(x, c->counter.p, sizeof x, hipMemcpyDeviceToHost);
+		fprintf(stderr, "[bvh stats] scans=%llu steps/scan=%.1f leaves/scan=%.1f\n", x[0], (double)x[1] / (double)(x[0] ? x[0] : 1), (double)x[2] / (double)(x[0] ? x[0] : 1));
+	}
+#endif
 #ifdef SP_FILTER_STATS
 	{
 		unsigned long long x[5] = {0, 0, 0, 0, 0};
