@@ -100,7 +100,9 @@ def main():
     ap.add_argument("--kernel", type=str, default="auto", help="scan kernel variant (see sphip_kernel_name)")
     ap.add_argument("--primary-reuse", action="store_true", help="scan the primary ray once per pixel (fewer scans; off for roofline runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-reference", action="store_true", help="skip the untimed exact-only scan reference run")
+    ap.add_argument("--extras", action="store_true", help="after the timed region also run (untimed, reduced spp) the exact-only scan, "
+                    "primary-hit reuse and the opt-in acceleration structure, and report them under reference_runs_untimed; "
+                    "off by default so that a profile of the default command contains only the timed kernel")
     ap.add_argument("--cpu-w", type=int, default=192)
     ap.add_argument("--cpu-h", type=int, default=108)
     ap.add_argument("--cpu-spp", type=int, default=16)
@@ -185,7 +187,7 @@ def main():
     # outside the timed region, for reference: the exact-only scan (every pair through the full Moeller-Trumbore test,
     # no conservative pre-test) on the same frame at 8 spp -- same image bits, ~4x the instructions per test
     exact_only = None
-    if world == 1 and NT >= 64 and not args.no_exact_reference:
+    if world == 1 and NT >= 64 and args.extras:
         spp_x = min(SPP, 8)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
