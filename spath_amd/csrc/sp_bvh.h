@@ -26,6 +26,8 @@ struct BvhArgs {
 	const int*    leaf_idx;  // original triangle index per sorted triangle, -1 for padding
 	uint32_t n_leaves;       // power of two
 	uint32_t first_leaf;     // == n_leaves (heap index of leaf 0)
+	uint32_t n_big;          // triangles too large for the tree (room walls, ground planes): sorted records [4*n_leaves, 4*n_leaves + n_big)
+	                         // are tested for every ray before the walk, which also gives the walk a tight cull distance from the start
 };
 
 // inclusive slab test; NaNs from 0 * inf drop out because v_min/v_max return the non-NaN operand
@@ -46,6 +48,14 @@ SP_DEV void scan_bvh(const BvhArgs& B, f3 o, f3 dir, int src, float& best_d, int
 	float bd = kMaxDist;
 	int bi = -1;
 	const f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	for (uint32_t j = 4u * B.n_leaves, e = 4u * B.n_leaves + B.n_big; j < e; ++j) {       // wave-uniform loop: scalar loads
+		const int orig = B.leaf_idx[j];
+		const float4 q0 = B.leaf_rec[3 * j], q1 = B.leaf_rec[3 * j + 1], q2 = B.leaf_rec[3 * j + 2];
+		const float d = ray_tri_strict(o, dir, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x));
+		const bool take = (orig != src) && (d > 0.0f) && ((d < bd) || (d == bd && orig < bi));
+		bd = take ? d : bd;
+		bi = take ? orig : bi;
+	}
 	uint32_t node = 1, trail = 0;
 	// Every step either descends one level or retires one pending sibling, so the walk visits each node at most once;
 	// the explicit bound is a belt-and-braces exit condition (a wave that never finishes can take the whole GPU down).

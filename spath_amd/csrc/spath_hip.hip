@@ -36,7 +36,7 @@ struct sphip_ctx {
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
 	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx;
 	bool bvh_valid = false;
-	uint32_t bvh_leaves = 0;
+	uint32_t bvh_leaves = 0, bvh_big = 0;
 	size_t n_tris = 0;
 	bool have_scene = false;
 	bool have_render = false, timed_upload = false, timed_download = false;
@@ -134,35 +134,60 @@ int ensure_bvh(sphip_ctx* c, hipStream_t st) {
 		for (int k = 0; k < 9; ++k) { const float v = t[i * 12 + k]; if (std::isfinite(v)) { lo[k % 3] = std::min(lo[k % 3], v); hi[k % 3] = std::max(hi[k % 3], v); } }
 	float ext[3], scale = 0.0f;
 	for (int a = 0; a < 3; ++a) { if (!(hi[a] >= lo[a])) { lo[a] = 0; hi[a] = 0; } ext[a] = hi[a] - lo[a]; scale = std::max(scale, std::max(std::fabs(lo[a]), std::fabs(hi[a]))); }
-	std::vector<std::pair<uint32_t, uint32_t>> order(n);
+	// triangles whose box spans more than a quarter of the scene (walls, ground planes) would put scene-sized boxes on
+	// whole root-to-leaf paths; up to kMaxBig of them (largest first) stay out of the tree and are tested for every ray
+	constexpr size_t kMaxBig = 256;
+	float max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
+	std::vector<std::pair<float, uint32_t>> bigs;
+	std::vector<char> is_big(n, 0);
 	for (size_t i = 0; i < n; ++i) {
+		float e = 0.0f;
+		for (int a = 0; a < 3; ++a) {
+			const float v0 = t[i * 12 + a], v1 = t[i * 12 + 3 + a], v2 = t[i * 12 + 6 + a];
+			e = std::max(e, std::max(v0, std::max(v1, v2)) - std::min(v0, std::min(v1, v2)));
+		}
+		if (!(e <= 0.25f * max_ext)) bigs.push_back({ -e, (uint32_t)i });          // also catches NaN extents
+	}
+	std::sort(bigs.begin(), bigs.end());
+	if (bigs.size() > kMaxBig) bigs.resize(kMaxBig);
+	for (auto& b : bigs) is_big[b.second] = 1;
+	const size_t n_tree = n - bigs.size();
+	std::vector<std::pair<uint32_t, uint32_t>> order;
+	order.reserve(n_tree);
+	for (size_t i = 0; i < n; ++i) {
+		if (is_big[i]) continue;
 		uint32_t code = 0;
 		for (int a = 0; a < 3; ++a) {
 			const float cen = (t[i * 12 + a] + t[i * 12 + 3 + a] + t[i * 12 + 6 + a]) * (1.0f / 3.0f);
 			const float u = ext[a] > 0 ? (cen - lo[a]) / ext[a] : 0.0f;
 			code |= morton10(std::isfinite(u) ? u : 0.0f) << a;
 		}
-		order[i] = { code, (uint32_t)i };
+		order.push_back({ code, (uint32_t)i });
 	}
 	std::sort(order.begin(), order.end());
-	const uint32_t l0 = (uint32_t)((n + 3) / 4);
+	const uint32_t l0 = (uint32_t)((n_tree + 3) / 4);
 	uint32_t nl = 1;
 	while (nl < l0) nl <<= 1;
-	std::vector<float> nodes((size_t)2 * nl * 8), rec((size_t)nl * 4 * 12, 0.0f);
-	std::vector<int> idx((size_t)nl * 4, -1);
+	std::vector<float> nodes((size_t)2 * nl * 8), rec(((size_t)nl * 4 + bigs.size()) * 12, 0.0f);
+	std::vector<int> idx((size_t)nl * 4 + bigs.size(), -1);
 	auto box = [&](uint32_t node) { return &nodes[(size_t)node * 8]; };   // lo.xyz hi.x | hi.yz pad pad
 	for (uint32_t node = 0; node < 2 * nl; ++node) { float* b = box(node); b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY; b[6] = b[7] = 0; }
-	for (size_t j = 0; j < n; ++j) {
-		const uint32_t i = order[j].second;
+	auto put_record = [&](size_t j, uint32_t i) {
 		const float* s = &t[(size_t)i * 12];
 		float* r = &rec[j * 12];
 		r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
 		r[3] = s[3] - s[0]; r[4] = s[4] - s[1]; r[5] = s[5] - s[2];      // e1, e2: the reference's float subtractions (geom.h:200-201)
 		r[6] = s[6] - s[0]; r[7] = s[7] - s[1]; r[8] = s[8] - s[2];
 		idx[j] = (int)i;
+	};
+	for (size_t j = 0; j < n_tree; ++j) {
+		const uint32_t i = order[j].second;
+		put_record(j, i);
+		const float* s = &t[(size_t)i * 12];
 		float* b = box(nl + (uint32_t)(j / 4));
 		for (int k = 0; k < 9; ++k) { const float v = s[k]; if (std::isfinite(v)) { b[k % 3] = std::min(b[k % 3], v); b[3 + k % 3] = std::max(b[3 + k % 3], v); } }
 	}
+	for (size_t k = 0; k < bigs.size(); ++k) put_record((size_t)nl * 4 + k, bigs[k].second);
 	// inflate the leaves (the slab test runs in float: keep every geometric hit inside), then refit bottom-up
 	for (uint32_t leaf = nl; leaf < 2 * nl; ++leaf) {
 		float* b = box(leaf);
@@ -183,6 +208,7 @@ int ensure_bvh(sphip_ctx* c, hipStream_t st) {
 	HIP_TRY(c, hipMemcpyAsync(c->bvh_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(c, hipStreamSynchronize(st));          // the staging vectors die with this call
 	c->bvh_leaves = nl;
+	c->bvh_big = (uint32_t)bigs.size();
 	c->bvh_valid = true;
 	return SPHIP_OK;
 }
@@ -244,7 +270,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	if (variant == kVariantAccel) {
 		if ((rc = ensure_bvh(c, st))) return rc;
 		B.nodes = (const float4*)c->bvh_nodes.p; B.leaf_rec = (const float4*)c->bvh_rec.p; B.leaf_idx = (const int*)c->bvh_idx.p;
-		B.n_leaves = c->bvh_leaves; B.first_leaf = c->bvh_leaves;
+		B.n_leaves = c->bvh_leaves; B.first_leaf = c->bvh_leaves; B.n_big = c->bvh_big;
 	}
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
 	if (variant == kVariantAccel) {
