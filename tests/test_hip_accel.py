@@ -83,3 +83,23 @@ def test_accel_speed_is_reported_separately(hip):
     print(f"\\naccel {ms_accel:.1f} ms vs brute force {ms_brute:.1f} ms for {w}x{h}x{spp}: {w*h*spp*5/ms_accel/1e3:.0f} vs {w*h*spp*5/ms_brute/1e3:.0f} nominal Mray/s; "
           f"pixels that differ (reference noise accepts): {frac:.2e}")
     assert frac <= 1e-3 and ms_accel < ms_brute
+
+
+def test_accel_ties_and_tiny_scenes(hip, O):
+    """Duplicate triangles (equal distances -> lowest original index), a single triangle, triangles nobody can hit."""
+    t0, m0 = scene.default_scene()
+    cases = {
+        "dups": (np.concatenate([t0, t0, t0[::-1]]), np.concatenate([m0, m0 * np.float32(0.5), m0[::-1]])),
+        "single": (t0[:1], m0[:1]),
+        "behind": (t0[:1] + np.array([0, 0, -50] * 3 + [0, 0, 0], dtype=np.float32), m0[:1]),
+        "five": (t0[:5], m0[:5]),
+    }
+    rays = view.Camera(64, 48).get_viewport()
+    for name, (t, m) in cases.items():
+        hip.set_scene(t, m)
+        want_i, want_d = O.closest_hits(rays, t)
+        ai, ad = _hits(hip, rays, capi.FLAG_ACCEL)
+        assert np.array_equal(ai, want_i) and np.array_equal(ad.view(np.uint32), want_d.view(np.uint32)), name
+        img, acc = hip.render(rays, 64, 48, 3, seed=2, flags=capi.FLAG_ACCEL, want_accum=True)
+        w_img, w_acc, _ = O.render_counter(rays, t, m, 3, 2)
+        assert np.array_equal(img, w_img) and np.array_equal(acc, w_acc), name
