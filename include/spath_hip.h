@@ -51,6 +51,12 @@ enum {
 	                                   every variant produces bit-identical images */
 	SPHIP_FLAG_PRIMARY_REUSE = 0x100,/* scan the (identical) primary ray of a pixel once for all its samples
 	                                   (src/cpu_renderer.cpp:74-76 re-scans it); identical image, fewer scans */
+	SPHIP_FLAG_CHUNKS_SHIFT = 16,   /* bits 16..23: number of sample chunks of a path-traced launch, 0 = let the library
+	                                   choose.  A frame (or shard) with too few pixels to fill the GPU several times over is
+	                                   launched as (pixel, sample chunk) lanes; each sample's radiance goes to a scratch buffer
+	                                   and a second kernel adds them up per pixel in sample order (src/cpu_renderer.cpp:74-76),
+	                                   so the image is bit-identical whatever the number of chunks.  1 = never split. */
+	SPHIP_FLAG_CHUNKS_MASK = 0xff0000,
 	SPHIP_FLAG_ACCEL = 0x200         /* OPT-IN acceleration structure (linear BVH).  Changes the work
 	                                   definition: the reference tests every triangle (README.md:23).  Same strict triangle
 	                                   test and tie rule, so every geometric hit is reproduced bit for bit; what it cannot

@@ -17,6 +17,13 @@ KERNEL_AUTO = 0
 FLAG_PRIMARY_REUSE = 0x100
 FLAG_ACCEL = 0x200          # opt-in linear BVH; not the brute-force path
 
+
+def flag_chunks(n: int) -> int:
+    """flags bits 16..23: number of sample chunks of a path-traced launch (0 = library's choice, 1 = never split)."""
+    if not 0 <= n <= 255:
+        raise ValueError("chunks must be in [0, 255]")
+    return n << 16
+
 # every entry point include/spath_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (
     "sphip_create", "sphip_destroy", "sphip_last_error", "sphip_description", "sphip_abi_version",

@@ -352,7 +352,10 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k0 = blockIdx.x * (256u * R) + tid;       // work-buffer slot of path r: k0 + r*256
 	const uint32_t kstep = SPLIT ? 0u : 256u;                // ray index of slot r: kr0 + r*kstep
-	const uint32_t kr0 = SPLIT ? blockIdx.x * 256u + tid : k0;
+	const bool chunked = a.n_chunks > 1;                     // blockIdx = chunk * px_blocks + pixel block
+	const uint32_t pblk = chunked ? blockIdx.x % a.px_blocks : blockIdx.x;
+	const uint32_t chunk = chunked ? blockIdx.x / a.px_blocks : 0u;
+	const uint32_t kr0 = SPLIT ? pblk * 256u + tid : pblk * (256u * R) + tid;
 	uint32_t pixel[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
@@ -384,7 +387,13 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 	}
 
 	const uint32_t n_iter = SPLIT ? (a.n_samples + R - 1) / R : a.n_samples;
-	for (uint32_t it = 0; it < n_iter; ++it) {
+	uint32_t it0 = 0, it1 = n_iter;
+	if (chunked) {
+		const uint32_t per = (n_iter + a.n_chunks - 1) / a.n_chunks;
+		it0 = chunk * per < n_iter ? chunk * per : n_iter;
+		it1 = it0 + per < n_iter ? it0 + per : n_iter;
+	}
+	for (uint32_t it = it0; it < it1; ++it) {
 		RaySlots<R> s;
 		int nh[R];                       // surface hits of this path so far
 		uint32_t smp[R];
@@ -447,7 +456,10 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 			}
 			// cpu_renderer.cpp:75 accum += sample, in sample order: with SPLIT the slots are consecutive samples of one
 			// pixel and are added to slot 0's accumulator one after the other (this loop is unrolled in order)
-			if (live[r]) {
+			if (live[r] && chunked) {
+				float* p = a.samp + (size_t)smp[r] * 3 * a.samp_stride + (kr0 + r * kstep);
+				p[0] = rec.x; p[a.samp_stride] = rec.y; p[(size_t)2 * a.samp_stride] = rec.z;
+			} else if (live[r]) {
 				const uint32_t ka = SPLIT ? k0 : kw;
 #pragma unroll
 				for (int c = 0; c < 3; ++c) {
@@ -461,7 +473,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 	for (int r = 0; r < (SPLIT ? 1 : R); ++r) {
 		const uint32_t k = kr0 + r * kstep;
 		const uint32_t kw = k0 + r * 256u;
-		if (k < a.n_rays) {
+		if (k < a.n_rays && !chunked) {
 			const f3 av = scale3(mk3(acc[kw], acc[(size_t)n_work + kw], acc[(size_t)2 * n_work + kw]), a.inv_n);
 			a.out_rgba[k] = vec3_rgba(mk3(clamp01(av.x), clamp01(av.y), clamp01(av.z)));
 			if (a.out_accum) {

@@ -24,7 +24,32 @@ struct KArgs {
 	uint64_t seed;
 	uint64_t pixel_base, tile_px, tile_stride_px;
 	float inv_n;               // float(1.0/n_samples), cpu_renderer.cpp:77
+	// sample chunks (filter kernels): blockIdx = chunk * px_blocks + pixel block; every sample's radiance is written to
+	// samp[(sample * 3 + c) * samp_stride + ray] and k_resolve adds them up in sample order.  n_chunks <= 1: off
+	uint32_t n_chunks, px_blocks, samp_stride;
+	float* samp;
 };
+
+// second pass of a sample-chunked launch: cpu_renderer.cpp:72-78 for one pixel -- zero, += sample in sample order,
+// * float(1.0/n_samples), clamp, quantise
+__global__ void __launch_bounds__(256) k_resolve(const KArgs a) {
+	const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+	if (k >= a.n_rays) return;
+	float ax = 0.0f, ay = 0.0f, az = 0.0f;
+	for (uint32_t s = 0; s < a.n_samples; ++s) {
+		const float* p = a.samp + (size_t)s * 3 * a.samp_stride + k;
+		ax = ax + p[0];
+		ay = ay + p[a.samp_stride];
+		az = az + p[(size_t)2 * a.samp_stride];
+	}
+	const f3 av = scale3(mk3(ax, ay, az), a.inv_n);
+	a.out_rgba[k] = vec3_rgba(mk3(clamp01(av.x), clamp01(av.y), clamp01(av.z)));
+	if (a.out_accum) {
+		a.out_accum[(size_t)k * 3 + 0] = av.x;
+		a.out_accum[(size_t)k * 3 + 1] = av.y;
+		a.out_accum[(size_t)k * 3 + 2] = av.z;
+	}
+}
 
 // ---- repack: AoS geom::triangle -> scan records.  e1/e2 are the single float subtractions of
 // geom.h:200-201, hoisted out of the per-ray test (same bits).

@@ -34,7 +34,7 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx;
 	bool bvh_valid = false;
 	uint32_t bvh_leaves = 0, bvh_big = 0;
 	size_t n_tris = 0;
@@ -76,6 +76,8 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 
 constexpr int kNumVariants = 7;       // selectable brute-force scan kernels; 8 = the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
 constexpr int kVariantAccel = 8;
+constexpr uint64_t kChunkTargetBlocks = 65536;          // 64 x the 1024 resident workgroups (measured: profiles/r01_sample_chunks.log)
+constexpr uint64_t kChunkMaxBytes = 16ull << 30;         // cap of the per-sample scratch buffer
 const char* const kVariantNames[kVariantAccel + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
                                                       "accel_lbvh" };
 
@@ -251,10 +253,29 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 
 	const int variant = pick_variant(flags, c->n_tris, n_rays, mode, n_samples);
 	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, 8 * sizeof(unsigned long long), st));
-	const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
-	const dim3 grid2((unsigned)((n_rays + 511) / 512)), grid4((unsigned)((n_rays + 1023) / 1024));
-	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray
-	const uint64_t n_work64 = (uint64_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u);
+	// sample chunks: the filter kernels keep 1024 workgroups resident (256 CUs x 4); a launch of only a few times that
+	// many ends with a long tail (its time is that of the slowest workgroup, ~12 % above the mean when everything starts
+	// together), so small frames and multi-GPU shards are split along the samples as well
+	uint32_t chunks = 1;
+	if (mode == SPHIP_MODE_PT && variant >= 3 && variant != kVariantAccel) {
+		const uint32_t rays_per_block = variant == 3 ? 512u : variant == 4 ? 1024u : 256u;
+		const uint64_t px_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
+		const uint64_t n_iter = variant == 7 ? (n_samples + 3) / 4 : variant == 6 ? (n_samples + 1) / 2 : n_samples;
+		const uint32_t forced = ((uint32_t)flags & SPHIP_FLAG_CHUNKS_MASK) >> SPHIP_FLAG_CHUNKS_SHIFT;
+		if (forced) chunks = forced;
+		else while (px_blocks * chunks < kChunkTargetBlocks && chunks < 128) chunks *= 2;
+		if (chunks > n_iter) chunks = (uint32_t)n_iter;
+		while (chunks > 1 && (uint64_t)n_samples * 12 * ((n_rays + 255) / 256 * 256) > kChunkMaxBytes) chunks = 1;   // scratch too large: do not split
+		if (chunks > 1) {
+			a.n_chunks = chunks; a.px_blocks = (uint32_t)px_blocks; a.samp_stride = (uint32_t)((n_rays + 255) / 256 * 256);
+			if ((rc = ensure(c, c->samp, (size_t)n_samples * 12 * a.samp_stride))) return rc;
+			a.samp = (float*)c->samp.p;
+		}
+	}
+	const dim3 grid((unsigned)((n_rays + 255) / 256 * chunks)), block(256);
+	const dim3 grid2((unsigned)((n_rays + 511) / 512 * chunks)), grid4((unsigned)((n_rays + 1023) / 1024 * chunks));
+	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray and chunk
+	const uint64_t n_work64 = (uint64_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u) * chunks;
 	if (mode == SPHIP_MODE_PT && variant >= 3 && n_work64 > 0xffffffffull)
 		return fail(c, SPHIP_E_INVALID, "n_rays %zu too large for one launch of this kernel variant; shard the frame", n_rays);
 	const uint32_t n_work = (uint32_t)n_work64;
@@ -299,6 +320,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_pt<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
 	}
+	if (chunks > 1) hipLaunchKernelGGL(sp::k_resolve, dim3((unsigned)((n_rays + 255) / 256)), block, 0, st, a);
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipEventRecord(c->ev_k1, st));
 	c->have_render = true;
@@ -306,7 +328,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	c->stats.n_tris = c->n_tris;
 	c->stats.n_pixels = n_rays;
 	c->stats.kernel_variant = (uint32_t)variant;
-	c->stats.n_launches = 1;
+	c->stats.n_launches = chunks > 1 ? 2 : 1;
 	return SPHIP_OK;
 }
 
@@ -358,7 +380,7 @@ void sphip_destroy(sphip_t* c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[13] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	DevBuf* bufs[14] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
 	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };

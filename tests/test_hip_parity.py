@@ -219,9 +219,35 @@ def test_primary_reuse_same_image_fewer_scans(hip, O):
     hip.set_scene(t, m)
     for v in VARIANTS:
         a_img, a_acc, a_st = render_pt(hip, rays, w, h, spp, 4, flags=v)
-        b_img, b_acc, b_st = render_pt(hip, rays, w, h, spp, 4, flags=v | capi.FLAG_PRIMARY_REUSE)
+        b_img, b_acc, b_st = render_pt(hip, rays, w, h, spp, 4, flags=v | capi.FLAG_PRIMARY_REUSE | capi.flag_chunks(1))
         assert np.array_equal(a_img, b_img) and np.array_equal(a_acc, b_acc)
         assert b_st["scans_executed"] == a_st["scans_executed"] - w * h * (spp - 1)
+        # with sample chunks (the library's choice for a frame this small) every chunk scans the primary ray once
+        c_img, c_acc, c_st = render_pt(hip, rays, w, h, spp, 4, flags=v | capi.FLAG_PRIMARY_REUSE)
+        assert np.array_equal(a_img, c_img) and np.array_equal(a_acc, c_acc)
+        assert b_st["scans_executed"] <= c_st["scans_executed"] <= a_st["scans_executed"]
+
+
+@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
+def test_sample_chunks_do_not_change_a_bit(hip, O, variant):
+    """A launch split into (pixel, sample chunk) lanes + the in-order resolve pass == the unsplit launch == the oracle."""
+    t, m = scene.closed_room(400)
+    w, h = 61, 37
+    rays = view.Camera(w, h).get_viewport()
+    hip.set_scene(t, m)
+    for spp in (7, 16):
+        want_img, want_acc, want_st = render_pt(hip, rays, w, h, spp, 11, flags=variant | capi.flag_chunks(1))
+        assert want_st["n_launches"] == 1
+        o_img, o_acc, o_scans = O.render_counter(rays, t, m, spp, 11)
+        assert np.array_equal(want_img, o_img) and np.array_equal(want_acc, o_acc) and want_st["scans_executed"] == o_scans
+        for ch in (0, 2, 3, 5, 64, 255):
+            img, acc, st = render_pt(hip, rays, w, h, spp, 11, flags=variant | capi.flag_chunks(ch))
+            assert np.array_equal(img, want_img) and np.array_equal(acc, want_acc), (spp, ch)
+            assert st["scans_executed"] == want_st["scans_executed"], (spp, ch)
+            assert st["n_launches"] == 2 or (ch == 0 and spp == 1)
+    # one sample cannot be split
+    img, acc, st = render_pt(hip, rays, w, h, 1, 11, flags=variant | capi.flag_chunks(8))
+    assert st["n_launches"] == 1 and np.array_equal(img, O.render_counter(rays, t, m, 1, 11)[0])
 
 
 def test_renderer_interface_mirror(hip, O, scenes):

@@ -1,4 +1,4 @@
-"""Speed of one 8-GPU shard (1/8 of a 1080p frame) with 1 vs 2 pixels per lane."""
+"""Speed of one rank's shard of a 1080p frame for 1/2/4/8-way row-tile splits (SPP env, default 8 spp)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,10 +9,11 @@ t, m = scene.closed_room(10000)
 d_t, d_m = torch.from_numpy(t).cuda(), torch.from_numpy(m).cuda()
 ctx.set_scene_device(d_t.data_ptr(), d_m.data_ptr(), 10000, 0)
 rays = view.Camera(1920, 1080).get_viewport()
-for world in (8, 1):
+spp = int(os.environ.get("SPP", "8"))
+for world in (8, 4, 2, 1):
     plan = RowTilePlan(1920, 1080, world, 8)
     sh = ShardedRenderer(ctx, plan, 0, rays, torch.device("cuda"))
     for var in (6,):
         for rep in range(2):
-            sh.render(8, flags=var); torch.cuda.synchronize(); st = ctx.stats()
-        print(f"world {world}: shard {sh.n} px, variant {var}->{st['kernel_variant']}: {st['kernel_ms']:.1f} ms, {st['scans_executed']*1e4/st['kernel_ms']/1e9:.3f} T tests/s", flush=True)
+            sh.render(spp, flags=var); torch.cuda.synchronize(); st = ctx.stats()
+        print(f"world {world}: {spp} spp, shard {sh.n} px, variant {var}->{st['kernel_variant']}: {st['kernel_ms']:.1f} ms, {st['scans_executed']*1e4/st['kernel_ms']/1e9:.3f} T tests/s", flush=True)
