@@ -76,7 +76,7 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 
 constexpr int kNumVariants = 7;       // selectable brute-force scan kernels; 8 = the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
 constexpr int kVariantAccel = 8;
-constexpr uint64_t kChunkTargetBlocks = 65536;          // 64 x the 1024 resident workgroups (measured: profiles/r01_sample_chunks.log)
+constexpr uint64_t kChunkTargetBlocks = 262144;         // 256 x the 1024 resident workgroups (measured: profiles/r01_sample_chunks.log)
 constexpr uint64_t kChunkMaxBytes = 16ull << 30;         // cap of the per-sample scratch buffer
 const char* const kVariantNames[kVariantAccel + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
                                                       "accel_lbvh" };
