@@ -265,10 +265,23 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		if (forced) chunks = forced;
 		else while (px_blocks * chunks < kChunkTargetBlocks && chunks < 128) chunks *= 2;
 		if (chunks > n_iter) chunks = (uint32_t)n_iter;
-		while (chunks > 1 && (uint64_t)n_samples * 12 * ((n_rays + 255) / 256 * 256) > kChunkMaxBytes) chunks = 1;   // scratch too large: do not split
+		const uint64_t samp_bytes = (uint64_t)n_samples * 12 * ((n_rays + 255) / 256 * 256);
+		if (chunks > 1 && !forced) {
+			// the split is an optimisation: it must never make a render fail that would fit unsplit (52 B per pixel).
+			// Keep the scratch under the cap and under 90 % of what the device has free beyond the cached buffers.
+			size_t free_b = 0, total_b = 0;
+			if (samp_bytes > kChunkMaxBytes || hipMemGetInfo(&free_b, &total_b) != hipSuccess) chunks = 1;
+			const uint64_t lanes = (uint64_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u);
+			while (chunks > 1) {
+				const uint64_t work_bytes = lanes * chunks * 52;
+				const uint64_t need = (samp_bytes > c->samp.cap ? samp_bytes : 0) + (work_bytes > c->work.cap ? work_bytes : 0);
+				if (need <= (uint64_t)((double)free_b * 0.9)) break;
+				chunks /= 2;
+			}
+		}
 		if (chunks > 1) {
 			a.n_chunks = chunks; a.px_blocks = (uint32_t)px_blocks; a.samp_stride = (uint32_t)((n_rays + 255) / 256 * 256);
-			if ((rc = ensure(c, c->samp, (size_t)n_samples * 12 * a.samp_stride))) return rc;
+			if ((rc = ensure(c, c->samp, (size_t)samp_bytes))) return rc;
 			a.samp = (float*)c->samp.p;
 		}
 	}

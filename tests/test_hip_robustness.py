@@ -122,3 +122,30 @@ def test_fuzz_filter_scan_against_exact_scan(hip):
         for var in (3, 5):
             assert np.array_equal(res[var][0], res[2][0]) and np.array_equal(res[var][1], res[2][1]), (it, var, n, size, spread)
         assert (res[2][0] >= 0).mean() > 0.02, (it, n, size, spread)     # the rays do hit things
+
+
+def test_sample_chunks_back_off_when_device_memory_is_short():
+    """The sample split is an optimisation: with (almost) no free device memory the same render must still succeed,
+    with fewer chunks or none, and give the same image."""
+    import torch
+    from spath_amd import view
+    t, m = scene.closed_room(300)
+    w, h, spp = 640, 360, 64
+    rays = view.Camera(w, h).get_viewport()
+    a = capi.Context(0)
+    a.set_scene(t, m)
+    want_img, want_acc = a.render(rays, w, h, spp, seed=3, want_accum=True)
+    assert a.stats()["n_launches"] == 2
+    del a
+    b = capi.Context(0)
+    b.set_scene(t, m)
+    b.render(rays, w, h, 1, seed=3)                       # buffers of the unsplit launch are allocated now
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (600 << 20), 0), dtype=torch.uint8, device="cuda")      # leave ~600 MB: the full split wants ~950 MB
+    try:
+        img, acc = b.render(rays, w, h, spp, seed=3, want_accum=True)
+        assert np.array_equal(img, want_img) and np.array_equal(acc, want_acc)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
