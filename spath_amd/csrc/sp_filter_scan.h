@@ -4,26 +4,32 @@
 // Stage 1 (every pair, 11 VALU): is the ray outside the slab spanned by the two lines that run parallel
 // to one edge of the triangle, one through that edge and one through the opposite vertex?  Written here
 // for edge2 (lines through v0 and v1); k_repack_filter picks the longest edge, i.e. the narrowest slab,
-// and the same argument holds for the v and u+v slabs.  With w = unit(e2),
-// P = pos x dir (ray moment, per ray), M0 = w x v0, M1 = w x v1 (per triangle):
-//     g0 = (pos - v0) . (dir x w) = w.P - dir.M0        g1 = (pos - v1) . (dir x w) = w.P - dir.M1
+// and the same argument holds for the v and u+v slabs.  With w = unit(e2) and
+// P = pos x dir (ray moment, per ray):
+//     g0 = (pos - v0) . (dir x w) = w.P - dir.(w x v0)        g1 = (pos - v1) . (dir x w) = w.P - dir.(w x v1)
 // g0 is the reference's s.h (geom.h:208) up to the factor |e2|, and g0 - g1 its a (geom.h:203).
 // geom::ray_intersect accepts only if u = f*(s.h) lies in [0,1] (geom.h:209), i.e. only if g0 and g1
 // have opposite signs up to rounding.  So: reject when they have the same sign and the smaller
-// magnitude exceeds an error margin Dq:   |med3(g0, g1, 0)| > Dq.
+// magnitude exceeds an error margin Dq.  The record stores the slab's MID-LINE and half-width,
+//     Mc = w x (v0 + v1)/2,   h = w x (v1 - v0)/2,      gm = w.P - dir.Mc,   t = dir.h,    g0 = gm + t,  g1 = gm - t,
+// which turns "same sign and min(|g0|, |g1|) > Dq" into   |gm| - |t| > Dq   : 9 multiply-adds, one subtract with
+// |.| source modifiers, one compare -- no v_med3_f32, which issues at about 60 % of the v_fma_f32 rate on gfx950
+// (tools/valu_bench.hip).
 //
 // Why this never rejects a pair the reference accepts (DESIGN.md section 4 has the full derivation):
 // let sh_f, a_f be the floats the strict evaluation produces.  Accepting needs 0 <= fl(fl(1/a_f)*sh_f)
 // <= 1, hence sh_f and (a_f - sh_f) have the same sign, or one of them is below 3u*|e1||dir||e2|.
 // Every quantity here is a sum of at most 9 products of bounded inputs, so with u = 2^-24
 //     |g0*|e2| - sh_f| and |(-g1)*|e2| - (a_f - sh_f)|  <=  36 u |e2| |dir| (|pos| + |v0| + |v1|)
-// (strict evaluation 7.6u + filter FMA chain 6u + rounding of P, M, w 7u + e1 = fl(v1-v0) 1.8u + the
-// relative slack of the u-comparisons 3u, each times the magnitude bound).  If g0, g1 share a sign and
+// (strict evaluation 7.6u + stage-1 evaluation 10u: six- and three-term FMA chains and the subtraction + rounding
+// of P, Mc, h, w 8u + e1 = fl(v1-v0) 1.8u + the relative slack of the u-comparisons 3u + normalisation 4u, each
+// times the magnitude bound).  If g0, g1 share a sign and
 // both exceed twice that bound, sh_f and a_f - sh_f provably have opposite signs and exceed the bound:
 // the reference rejects.  Dq is set to 2^-16 |dir|_1 (|pos|_1 + 2 Rv) >= 2 * 36u * (...) with the
 // 1-norms over-estimating the 2-norms and Rv = max vertex norm of the scene; it is per ray, exact
 // |pos| and |dir| of that ray, so there is no assumption on where rays start.  The compare is the
-// NaN-safe !(x > Dq): any overflow or NaN in stage 1 makes the pair a survivor.
+// NaN-safe !(x > Dq): a NaN in stage 1 makes the pair a survivor, and a ray whose magnitudes could make a
+// stage-1 product overflow (|dir|_1 (|pos|_1 + 2 Rv) >= 1e37, or NaN) gets Dq = inf: everything survives.
 //
 // Stage 2: survivors (about 1 % of pairs for small triangles) are queued per lane in LDS and run
 // through ray_tri_strict (sp_device_math.h) in index order at the end of each triangle tile, so the
@@ -50,19 +56,19 @@ static_assert(kFlushTiles * 256u <= (1u << kIdxBits), "queue index bits");
 constexpr int kQCap = SP_QCAP;   // queue entries per lane (u16); 12 KB, keeps 4 workgroups per CU
 
 // filter record: 48 B = 3 x float4, produced by k_repack_filter
-//   q0 = w.x w.y w.z M0.x   q1 = M0.y M0.z M1.x M1.y   q2 = M1.z 0 0 0
+//   q0 = w.x w.y w.z Mc.x   q1 = Mc.y Mc.z h.x h.y   q2 = h.z 0 0 0
 __global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__ tris, float4* __restrict__ filt,
                                                       unsigned int* __restrict__ bounds, uint32_t n, uint32_t n_padded) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_padded) return;
 	if (i >= n) {
-		// padding behind the last triangle (the filter loop reads whole groups of 2-4 records): w = 0, M0 = M1 = (H,H,H)
-		// gives g0 = g1 = -H (dx+dy+dz), same sign and huge, i.e. rejected unless dx+dy+dz is ~0; a padding record that
+		// padding behind the last triangle (the filter loop reads whole groups of 2-4 records): w = 0, Mc = (H,H,H), h = 0
+		// gives gm = -H (dx+dy+dz), t = 0: huge, i.e. rejected unless dx+dy+dz is ~0; a padding record that
 		// does survive meets a zero exact record (a = 0) in stage 2 and is rejected there
 		const float H = 1e30f;
 		filt[(size_t)i * 3 + 0] = make_float4(0.0f, 0.0f, 0.0f, H);
-		filt[(size_t)i * 3 + 1] = make_float4(H, H, H, H);
-		filt[(size_t)i * 3 + 2] = make_float4(H, 0.0f, 0.0f, 0.0f);
+		filt[(size_t)i * 3 + 1] = make_float4(H, H, 0.0f, 0.0f);
+		filt[(size_t)i * 3 + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		return;
 	}
 	const float* t = tris + (size_t)i * 12;
@@ -85,11 +91,15 @@ __global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__
 	const double len = sqrt(len2);
 	const float wx = (float)(w3[0] / len), wy = (float)(w3[1] / len), wz = (float)(w3[2] / len);   // NaN for a degenerate triangle: always survives
 	const double dwx = wx, dwy = wy, dwz = wz;
-	const float m0x = (float)(dwy * p0[2] - dwz * p0[1]), m0y = (float)(dwz * p0[0] - dwx * p0[2]), m0z = (float)(dwx * p0[1] - dwy * p0[0]);
-	const float m1x = (float)(dwy * p1[2] - dwz * p1[1]), m1y = (float)(dwz * p1[0] - dwx * p1[2]), m1z = (float)(dwx * p1[1] - dwy * p1[0]);
-	filt[(size_t)i * 3 + 0] = make_float4(wx, wy, wz, m0x);
-	filt[(size_t)i * 3 + 1] = make_float4(m0y, m0z, m1x, m1y);
-	filt[(size_t)i * 3 + 2] = make_float4(m1z, 0.0f, 0.0f, 0.0f);
+	// mid-point and half-difference of the two slab lines' anchor points, in double (exact for float inputs up to
+	// 29 binades apart), crossed with w and rounded once
+	const double pc[3] = { 0.5 * (p0[0] + p1[0]), 0.5 * (p0[1] + p1[1]), 0.5 * (p0[2] + p1[2]) };
+	const double ph[3] = { 0.5 * (p1[0] - p0[0]), 0.5 * (p1[1] - p0[1]), 0.5 * (p1[2] - p0[2]) };
+	const float mcx = (float)(dwy * pc[2] - dwz * pc[1]), mcy = (float)(dwz * pc[0] - dwx * pc[2]), mcz = (float)(dwx * pc[1] - dwy * pc[0]);
+	const float hx = (float)(dwy * ph[2] - dwz * ph[1]), hy = (float)(dwz * ph[0] - dwx * ph[2]), hz = (float)(dwx * ph[1] - dwy * ph[0]);
+	filt[(size_t)i * 3 + 0] = make_float4(wx, wy, wz, mcx);
+	filt[(size_t)i * 3 + 1] = make_float4(mcy, mcz, hx, hy);
+	filt[(size_t)i * 3 + 2] = make_float4(hz, 0.0f, 0.0f, 0.0f);
 	// scene bound Rv >= every vertex norm, as 1-norms (>= 2-norm); non-negative floats order like their bit patterns;
 	// a NaN or inf coordinate yields a bit pattern >= inf, which turns the filter off in the kernels
 	float r = 0.0f;
@@ -134,18 +144,17 @@ SP_DEV void tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, 
 }
 
 // stage 1 for one (triangle record, ray): true = survivor
-SP_DEV bool slab_survives(const float4 q0, const float4 q1, const float m1z, const f3 P, const f3 dir, const float dq) {
-	float A = q0.x * P.x;
-	A = __builtin_fmaf(q0.y, P.y, A);
-	A = __builtin_fmaf(q0.z, P.z, A);
-	float g0 = __builtin_fmaf(-dir.x, q0.w, A);
-	g0 = __builtin_fmaf(-dir.y, q1.x, g0);
-	g0 = __builtin_fmaf(-dir.z, q1.y, g0);
-	float g1 = __builtin_fmaf(-dir.x, q1.z, A);
-	g1 = __builtin_fmaf(-dir.y, q1.w, g1);
-	g1 = __builtin_fmaf(-dir.z, m1z, g1);
-	const float m = __builtin_amdgcn_fmed3f(g0, g1, 0.0f);
-	return !(fabsf(m) > dq);          // NaN-safe: anything unordered survives
+SP_DEV bool slab_survives(const float4 q0, const float4 q1, const float hz, const f3 P, const f3 dir, const float dq) {
+	float gm = q0.x * P.x;
+	gm = __builtin_fmaf(q0.y, P.y, gm);
+	gm = __builtin_fmaf(q0.z, P.z, gm);
+	gm = __builtin_fmaf(-dir.x, q0.w, gm);
+	gm = __builtin_fmaf(-dir.y, q1.x, gm);
+	gm = __builtin_fmaf(-dir.z, q1.y, gm);
+	float t = dir.x * q1.z;
+	t = __builtin_fmaf(dir.y, q1.w, t);
+	t = __builtin_fmaf(dir.z, hz, t);
+	return !(fabsf(gm) - fabsf(t) > dq);          // NaN-safe: anything unordered (NaN, inf - inf) survives
 }
 
 // Closest hit for the R rays of every lane.  Block-uniform call (barriers inside).
@@ -165,7 +174,10 @@ SP_DEV void scan_filter(const KArgs& a, const float4* __restrict__ filt, float r
 		P[r] = cross3(s.o[r], s.dir[r]);
 		const float dn = fabsf(s.dir[r].x) + fabsf(s.dir[r].y) + fabsf(s.dir[r].z);
 		const float on = fabsf(s.o[r].x) + fabsf(s.o[r].y) + fabsf(s.o[r].z);
-		const float m = 0x1p-16f * 1.01f * dn * (on + 2.0f * rv);
+		// every product of stage 1 is bounded by mag, a sum of six by 6 mag: below 1e37 nothing can overflow; beyond
+		// (or NaN) the filter is switched off for this ray rather than trusted with infinities
+		const float mag = dn * (on + 2.0f * rv);
+		const float m = mag < 1e37f ? 0x1p-16f * 1.01f * mag : __builtin_inff();
 		// inactive slot: margin -1 -> "|m| > -1" always true -> always rejected.  A non-finite margin
 		// (huge or NaN inputs) fails the '>' test for every pair -> everything survives -> exact path.
 		Dq[r] = s.act[r] ? m : -1.0f;

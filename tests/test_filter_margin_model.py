@@ -2,10 +2,10 @@
 
 For random and adversarial (ray, triangle) pairs it evaluates, in float32 numpy with the reference's operation
 order, the quantities the strict test computes (a_f, sh_f = s.h, vq_f = dir.q) and, with an emulated float32
-FMA chain, the filter's g0, g1 for each of the three slabs, and checks
+FMA chain, the filter's gm, t (g0 = gm + t, g1 = gm - t) for each of the three slabs, and checks
   1. the measured discrepancy |g0*|base| - strict value| stays far below the bound D = 36u |dir| (|pos|+|v0|+|v1|)
      the derivation allows (44u for the third slab), and
-  2. the filter decision  |med3(g0, g1, 0)| > Dq  never fires on a pair the strict test accepts.
+  2. the filter decision  fl(|gm| - |t|) > Dq  never fires on a pair the strict test accepts.
 """
 import numpy as np
 
@@ -46,22 +46,23 @@ def strict(pos, d, v0, v1, v2):
 
 
 def filter_g(pos, d, w, p0, p1):
-    """k_repack_filter + slab_survives arithmetic: records rounded to float32, g by an FMA chain."""
+    """k_repack_filter + slab_survives arithmetic: mid-line records rounded to float32, gm and t by FMA chains."""
     wn = (w / np.linalg.norm(w, axis=1, keepdims=True)).astype(F)
     wd = wn.astype(np.float64)
-    M0 = np.cross(wd, p0.astype(np.float64)).astype(F)
-    M1 = np.cross(wd, p1.astype(np.float64)).astype(F)
+    p0d, p1d = p0.astype(np.float64), p1.astype(np.float64)
+    Mc = np.cross(wd, 0.5 * (p0d + p1d)).astype(F)
+    h = np.cross(wd, 0.5 * (p1d - p0d)).astype(F)
     P = cross(pos, d)
-    A = wn[:, 0] * P[:, 0]
-    A = fma(wn[:, 1], P[:, 1], A)
-    A = fma(wn[:, 2], P[:, 2], A)
-    g = []
-    for M in (M0, M1):
-        x = fma(-d[:, 0], M[:, 0], A)
-        x = fma(-d[:, 1], M[:, 1], x)
-        x = fma(-d[:, 2], M[:, 2], x)
-        g.append(x)
-    return g[0], g[1]
+    gm = wn[:, 0] * P[:, 0]
+    gm = fma(wn[:, 1], P[:, 1], gm)
+    gm = fma(wn[:, 2], P[:, 2], gm)
+    gm = fma(-d[:, 0], Mc[:, 0], gm)
+    gm = fma(-d[:, 1], Mc[:, 1], gm)
+    gm = fma(-d[:, 2], Mc[:, 2], gm)
+    t = d[:, 0] * h[:, 0]
+    t = fma(d[:, 1], h[:, 1], t)
+    t = fma(d[:, 2], h[:, 2], t)
+    return gm, t
 
 
 def make_pairs(rng, n):
@@ -101,7 +102,8 @@ def test_error_model_and_conservativeness():
     chosen = np.where((l2 >= l1) & (l2 >= lc), "u", np.where(l1 >= lc, "v", "w"))      # k_repack_filter's rule: the longest edge
     seen = 0
     for name, (w, p0, p1, x0, x1, bound_u) in slabs.items():
-        g0, g1 = filter_g(pos, d, w.astype(F), p0, p1)
+        gm, t = filter_g(pos, d, w.astype(F), p0, p1)
+        g0, g1 = gm.astype(np.float64) + t.astype(np.float64), gm.astype(np.float64) - t.astype(np.float64)
         base = np.linalg.norm(w.astype(np.float64), axis=1)
         if name == "w":
             X = sh.astype(np.float64) + vq.astype(np.float64)          # sh + dir.q = s.(dir x c) = (pos-v0).(dir x c)
@@ -109,12 +111,12 @@ def test_error_model_and_conservativeness():
             x0, x1 = X - a.astype(np.float64), -X
         ok = np.isfinite(g0) & np.isfinite(g1) & (base > 0) & (chosen == name)       # each slab is only ever used on its own triangles
         seen += int(ok.sum())
-        r0 = np.abs(g0[ok].astype(np.float64) * base[ok] - x0[ok]) / (U * base[ok] * mag[ok])
-        r1 = np.abs((-g1[ok]).astype(np.float64) * base[ok] - x1[ok]) / (U * base[ok] * mag[ok])
+        r0 = np.abs(g0[ok] * base[ok] - x0[ok]) / (U * base[ok] * mag[ok])
+        r1 = np.abs((-g1[ok]) * base[ok] - x1[ok]) / (U * base[ok] * mag[ok])
         assert r0.max() < bound_u and r1.max() < bound_u, (name, r0.max(), r1.max())
         assert max(r0.max(), r1.max()) < 12.0, (name, r0.max(), r1.max())     # in practice an order of magnitude below the bound
-        med = np.where((g0 > 0) & (g1 > 0), np.minimum(g0, g1), np.where((g0 < 0) & (g1 < 0), np.maximum(g0, g1), F(0)))
-        reject = np.abs(med.astype(np.float64)) > Dq
+        with np.errstate(all="ignore"):
+            reject = (np.abs(gm) - np.abs(t)).astype(np.float64) > Dq          # float32 subtraction, as slab_survives does it
         assert not (reject & acc & ok).any(), (name, int((reject & acc & ok).sum()))
         assert reject[ok].mean() > 0.1                                        # and it does reject
         print(f"slab {name}: {int(ok.sum())} pairs, max discrepancy {max(r0.max(), r1.max()):.2f} u (bound {bound_u:.0f} u), "

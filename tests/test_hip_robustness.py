@@ -45,6 +45,19 @@ def test_scaled_and_shifted_scenes(hip, O, scale, shift):
         assert (idx >= 0).mean() > 0.9
 
 
+@pytest.mark.parametrize("scale,dir_len", [(1e18, 1e18), (1e19, 1e19), (3e18, 3e19), (1e10, 1e27), (1e-3, 3e38), (1e19, 1.0)])
+def test_products_near_float_overflow(hip, O, scale, dir_len):
+    """|pos| |dir| around 1e36 .. 1e39: stage-1 products reach the float range.  Below 1e37 nothing can overflow, from
+    there on the filter switches itself off for the ray (Dq = inf); either way the hits must be the strict evaluation's."""
+    t, m = scene.closed_room(400)
+    t = t.copy()
+    t[:, :9] = (t[:, :9].astype(np.float64) * scale).astype(np.float32)
+    hip.set_scene(t, m)
+    rays = _rays(np.random.default_rng(12), 3000, scale, 0.0)
+    rays[:, 3:] = (rays[:, 3:].astype(np.float64) * dir_len * np.random.default_rng(13).uniform(0.1, 1.0, (3000, 1))).astype(np.float32)
+    _hits(hip, O, t, rays, (scale, dir_len))
+
+
 def test_nonfinite_and_degenerate_inputs(hip, O):
     t, m = scene.closed_room(300)
     t = t.copy()
