@@ -59,6 +59,51 @@ __global__ void __launch_bounds__(256) k(float* out, float sa, float sb) {
 #define OP(x) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
 			OP(x0) OP(x1) OP(x2) OP(x3) OP(x4) OP(x5) OP(x6) OP(x7)
 #undef OP
+		} else if (MODE == 10) { // v_fma_f32, one dependent chain (ILP 1)
+#define OP(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+			OP(x0) OP(x0) OP(x0) OP(x0) OP(x0) OP(x0) OP(x0) OP(x0)
+#undef OP
+		} else if (MODE == 11) { // v_fma_f32, two dependent chains (ILP 2)
+#define OP(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+			OP(x0) OP(x1) OP(x0) OP(x1) OP(x0) OP(x1) OP(x0) OP(x1)
+#undef OP
+		} else if (MODE == 12) { // v_fmac_f32 (VOP2 encoding), 8 chains
+#define OP(x) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+			OP(x0) OP(x1) OP(x2) OP(x3) OP(x4) OP(x5) OP(x6) OP(x7)
+#undef OP
+		} else if (MODE == 13) { // v_fmac_f32, two chains
+#define OP(x) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+			OP(x0) OP(x1) OP(x0) OP(x1) OP(x0) OP(x1) OP(x0) OP(x1)
+#undef OP
+		} else if (MODE == 14) { // v_sub_f32 with |.| modifiers (VOP3)
+#define OP(x) asm volatile("v_sub_f32 %0, |%0|, |%1|" : "+v"(x) : "v"(a));
+			OP(x0) OP(x1) OP(x2) OP(x3) OP(x4) OP(x5) OP(x6) OP(x7)
+#undef OP
+		} else if (MODE == 15) { // v_cmp_ngt_f32 into an SGPR pair + s_or_b64
+			unsigned long long m0, m1;
+#define OP(x, m) asm volatile("v_cmp_ngt_f32 %0, %1, %2" : "=s"(m) : "v"(x), "v"(a));
+			OP(x0, m0) OP(x1, m1) m0 |= m1; OP(x2, m1) m0 |= m1; OP(x3, m1) m0 |= m1; OP(x4, m1) m0 |= m1; OP(x5, m1) m0 |= m1; OP(x6, m1) m0 |= m1; OP(x7, m1) m0 |= m1;
+#undef OP
+			if (m0 == 0x123456789ull) x0 += 1.0f;
+		} else if (MODE == 16) { // 8 x v_cmp_ngt_f32 into distinct SGPR pairs, no SALU use inside the loop
+			unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+#define OP(x, m) asm volatile("v_cmp_ngt_f32 %0, %1, %2" : "=s"(m) : "v"(x), "v"(a));
+			OP(x0, m0) OP(x1, m1) OP(x2, m2) OP(x3, m3) OP(x4, m4) OP(x5, m5) OP(x6, m6) OP(x7, m7)
+#undef OP
+			asm volatile("" :: "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7));
+		} else if (MODE == 17) { // v_cmp_ngt_f32 vcc + v_addc_co_u32 (per-lane bit mask), counted as 2 per pair
+			unsigned int mask = 0;
+#define OP(x) asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(x), "v"(a) : "vcc");
+			OP(x0) OP(x1) OP(x2) OP(x3)
+#undef OP
+			if (mask == 0x12345u) x0 += 1.0f;
+		} else if (MODE == 18) { // 8 x v_cmp into SGPR pairs + balanced s_or tree (7 s_or, no serial chain)
+			unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+#define OP(x, m) asm volatile("v_cmp_ngt_f32 %0, %1, %2" : "=s"(m) : "v"(x), "v"(a));
+			OP(x0, m0) OP(x1, m1) OP(x2, m2) OP(x3, m3) OP(x4, m4) OP(x5, m5) OP(x6, m6) OP(x7, m7)
+#undef OP
+			const unsigned long long r = ((m0 | m1) | (m2 | m3)) | ((m4 | m5) | (m6 | m7));
+			if (r == 0x123456789ull) x0 += 1.0f;
 		}
 	}
 	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y
@@ -98,6 +143,15 @@ int main() {
 		run<7>("v_pk_mul_f32 sgpr-pair operand", 8, bpc, d_out);
 		run<8>("v_mul_f32", 8, bpc, d_out);
 		run<9>("v_med3_f32", 8, bpc, d_out);
+		run<10>("v_fma_f32 one chain", 8, bpc, d_out);
+		run<11>("v_fma_f32 two chains", 8, bpc, d_out);
+		run<12>("v_fmac_f32 (VOP2) 8 chains", 8, bpc, d_out);
+		run<13>("v_fmac_f32 (VOP2) two chains", 8, bpc, d_out);
+		run<14>("v_sub_f32 |a|,|b| (VOP3)", 8, bpc, d_out);
+		run<15>("v_cmp_ngt_f32 -> sgpr + s_or_b64", 8, bpc, d_out);
+		run<16>("v_cmp_ngt_f32 -> 8 sgpr pairs", 8, bpc, d_out);
+		run<17>("v_cmp vcc + v_addc_co_u32", 8, bpc, d_out);
+		run<18>("v_cmp -> sgpr + s_or tree", 8, bpc, d_out);
 	}
 	return 0;
 }
