@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--tris", type=int, default=10000)
-    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--tile-rows", type=int, default=0, help="rows per tile of the round-robin shard plan; 0 = largest height <= 8 that balances the ranks")
     ap.add_argument("--kernel", type=str, default="auto", help="scan kernel variant (see sphip_kernel_name)")
     ap.add_argument("--primary-reuse", action="store_true", help="scan the primary ray once per pixel (fewer scans; off for roofline runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +112,7 @@ def main():
     import torch
     import torch.distributed as dist
     from spath_amd import capi, scene, view
-    from spath_amd.dist import RowTilePlan, ShardedRenderer, gather_to_root
+    from spath_amd.dist import RowTilePlan, ShardedRenderer, balanced_tile_rows, gather_to_root
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -140,6 +140,8 @@ def main():
     W, H, SPP, NT = args.width, args.height, args.spp, args.tris
     tris, mats = scene.closed_room(NT)
     rays = view.Camera(W, H).get_viewport()
+    if args.tile_rows <= 0:
+        args.tile_rows = balanced_tile_rows(H, world)
     plan = RowTilePlan(W, H, world, args.tile_rows)
 
     ctx = capi.Context(dev_index)

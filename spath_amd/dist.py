@@ -13,6 +13,15 @@ from __future__ import annotations
 import numpy as np
 
 
+def balanced_tile_rows(height: int, world_size: int, max_rows: int = 8) -> int:
+    """Largest tile height <= max_rows that deals every rank the same number of full tiles (so that equal-cost pixels give
+    equal shards); max_rows if there is none.  1080 rows on 8 ranks: 5 (216 tiles, 27 each) instead of 8 (17/16 tiles)."""
+    for tr in range(max_rows, 0, -1):
+        if height % tr == 0 and (height // tr) % world_size == 0:
+            return tr
+    return max_rows
+
+
 class RowTilePlan:
     def __init__(self, width: int, height: int, world_size: int, tile_rows: int = 8):
         if min(width, height, world_size, tile_rows) < 1:

@@ -75,3 +75,13 @@ def test_plan_covers_every_pixel_once():
         # balance: no rank holds more than one tile more than another
         n = [plan.n_rays(k) for k in range(g)]
         assert max(n) - min(n) <= plan.tile_px
+
+
+def test_balanced_tile_rows():
+    """bench.py's default tile height: every rank gets the same number of pixels when the image allows it."""
+    from spath_amd.dist import balanced_tile_rows
+    for h, g in [(1080, 1), (1080, 2), (1080, 4), (1080, 8), (2160, 8), (720, 8)]:
+        tr = balanced_tile_rows(h, g)
+        plan = RowTilePlan(64, h, g, tr)
+        assert 1 <= tr <= 8 and len({plan.n_rays(r) for r in range(g)}) == 1, (h, g, tr)
+    assert balanced_tile_rows(1081, 8) == 8            # nothing balances a prime height: keep the default
