@@ -79,7 +79,7 @@ def test_plan_covers_every_pixel_once():
 
 def test_balanced_tile_rows():
     """bench.py's default tile height: every rank gets the same number of pixels when the image allows it."""
-    from spath_amd.dist import balanced_tile_rows
+    from spath_amd.dist import RowTilePlan, balanced_tile_rows
     for h, g in [(1080, 1), (1080, 2), (1080, 4), (1080, 8), (2160, 8), (720, 8)]:
         tr = balanced_tile_rows(h, g)
         plan = RowTilePlan(64, h, g, tr)
