@@ -1,7 +1,8 @@
 // Kernels of the spath hot path for gfx950 (CDNA4): triangle repack, flat pass, path tracer.
 //
-// Work decomposition: one lane owns one pixel for the whole integrator
-// (samples are accumulated in the reference's order, cpu_renderer.cpp:74-76), a wavefront walks 64
+// Work decomposition: one lane owns one pixel for the whole integrator -- or, in a
+// sample-chunked launch of the filter kernels, for one contiguous range of its samples, with k_resolve adding
+// the per-sample results up -- so samples are accumulated in the reference's order (cpu_renderer.cpp:74-76); a wavefront walks 64
 // paths in lock-step through the (wave-uniform) depth loop, and the closest-hit scan streams the
 // repacked triangle array once per (wave, bounce).
 #pragma once

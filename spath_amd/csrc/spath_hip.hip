@@ -87,10 +87,10 @@ int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_sam
 	if (v >= 1 && v <= kNumVariants) return v;
 	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
 	// Path tracing with >= 2 spp: two consecutive SAMPLES of a pixel per lane (rpl_filter2s).  It halves the LDS reads
-	// per test like two pixels per lane do, keeps 256 pixels per workgroup so that small shards (8-GPU row tiles of
-	// a 1080p frame: 1020 workgroups) still fill the 256 CUs x 4 workgroup slots, and measured fastest at every
-	// shard size (profiles/r01_shard_speed.log).  One scan per ray (flat pass, 1 spp): two pixels per lane when
-	// that still leaves >= ~768 workgroups, else one.
+	// per test like two pixels per lane do and keeps 256 pixels per workgroup; with sample chunks (launch_render) every
+	// filter variant gets enough workgroups and all run at the same VALU-bound rate, this one never slower
+	// (profiles/r01_shard_speed.log, r01_sample_chunks.log).  One scan per ray (flat pass, 1 spp): two pixels per lane
+	// when that still leaves >= ~768 workgroups, else one.
 	if (mode == SPHIP_MODE_PT && n_samples >= 2) return 6;
 	return n_rays >= 384u * 1024u ? 3 : 5;
 }
