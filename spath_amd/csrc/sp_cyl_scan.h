@@ -1,0 +1,332 @@
+// Two-stage closest-hit scan, second generation ("rpl_cyl"): a 7-instruction conservative reject per (ray, triangle),
+// survivors remembered as ONE BIT per (4-triangle group, ray) in a per-lane register word, the reference's exact
+// Moeller-Trumbore (ray_tri_strict) for the bits that are set.  Bit-identical results.
+//
+// Stage 1.  sp_filter_scan.h rejects a pair when the ray misses the slab spanned by the triangle's longest edge and
+// the parallel line through the opposite vertex:  |gm| - |t| > Dq  with  gm = w.P - dir.Mc  (6 multiply-adds),
+// t = dir.h (3), P = pos x dir, w = unit(longest edge), Mc = w x (mid-point of the two lines' anchors), h = w x
+// (their half-difference); DESIGN.md section 4 proves that this never rejects a pair geom::ray_intersect accepts
+// (geom.h:197-222).  Here |t| is replaced by an upper bound that costs one multiply-add instead of three,
+//     |t| = |dir.h| <= |dir|_2 |h|_2 =: D * H          (H per triangle, D per ray, both rounded up),
+//     reject  <=>  |gm| - H*D > Dq,
+// geometrically "the ray misses the infinite cylinder of radius (triangle height)/2 around the slab's mid-line".
+// Whatever this rejects the slab test rejects too, so conservativeness is inherited (DESIGN.md section 4.2 does the
+// rounding bookkeeping).  And w is scaled so that its LARGEST component is exactly 1: that product needs no
+// multiplication, the chain starts from the ray-moment component itself -- 5 multiply-adds for gm.  Triangles are
+// therefore streamed in three classes (dominant axis x, y, z; k_cyl_scatter), the kernel rotating (P.x,P.y,P.z)
+// between classes; the stream order is no longer the index order, which is why stage 2 compares (d, index)
+// lexicographically -- the same closest hit and the same tie rule as "ascending index, first strictly smaller d wins"
+// (cpu_renderer.cpp:39-49).
+//
+// Survivor bookkeeping.  About twice as many pairs survive the cylinder test as the slab test (0.5 % against 0.24 % at
+// BASELINE configs[2]), and in the first generation it was the bookkeeping, not the arithmetic, that cost: a wave-level
+// branch per 8 pairs, taken 70 % of the time, with eight compare-and-push blocks behind it, and an LDS queue per lane.
+// Here each lane folds the four x = |gm| - H*D of a group into their minimum, subtracts the margin and shifts the SIGN
+// BIT of the difference into a 32-bit word (v_min3_f32, v_min_f32, v_sub_f32, v_alignbit_b32: one instruction per pair,
+// no branch, no VCC, no LDS).  At the end of a 256-triangle tile every lane walks its set bits: re-reads the group's
+// four records (per-lane LDS addresses), recomputes the four x, and runs ray_tri_strict on each survivor.  There is no
+// queue, hence no overflow: a scene of huge triangles degrades smoothly to the exact-only scan.
+//
+// record: 32 B = 2 x float4 (class a, with (a,b,c) a cyclic rotation of (x,y,z)):
+//   q0 = w_b/w_a  w_c/w_a  Mc.x/w_a  Mc.y/w_a        q1 = Mc.z/w_a  H/|w_a|  bits(original index)  0
+#pragma once
+
+#include "sp_kernels.h"
+#include "sp_filter_scan.h"
+
+namespace sp {
+
+constexpr uint32_t kCylTileQ = 2u * kTile;        // float4 per 256-triangle tile (8 KB)
+
+struct CylStream {
+	const float4* rec;       // class-major stream; every class starts on a tile boundary
+	const uint32_t* hdr;     // [0..2] triangles per class, [3..5] first tile of each class (k_cyl_offsets)
+};
+
+// ---- record of one triangle (double arithmetic, each coefficient rounded once).  Returns the class.
+SP_DEV int cyl_record(const float* __restrict__ t, uint32_t idx, float4& q0, float4& q1) {
+	const double A[3] = { t[0], t[1], t[2] }, B[3] = { t[3], t[4], t[5] }, C[3] = { t[6], t[7], t[8] };
+	// e1, e2 exactly as the reference rounds them (geom.h:200-201); c = e2 - e1 is the third edge
+	const double e1[3] = { (double)(t[3] - t[0]), (double)(t[4] - t[1]), (double)(t[5] - t[2]) };
+	const double e2[3] = { (double)(t[6] - t[0]), (double)(t[7] - t[1]), (double)(t[8] - t[2]) };
+	const double c[3] = { e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2] };
+	const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+	const double l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+	const double lc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+	// narrowest slab = along the longest edge (sp_filter_scan.h, k_repack_filter)
+	const double* w3; const double* p0; const double* p1; double len2;
+	if (l2 >= l1 && l2 >= lc) { w3 = e2; p0 = A; p1 = B; len2 = l2; }
+	else if (l1 >= lc)        { w3 = e1; p0 = A; p1 = C; len2 = l1; }
+	else                      { w3 = c;  p0 = B; p1 = A; len2 = lc; }
+	const double len = sqrt(len2);
+	const double w[3] = { w3[0] / len, w3[1] / len, w3[2] / len };
+	const double ax = fabs(w[0]), ay = fabs(w[1]), az = fabs(w[2]);
+	const int a = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+	const int b = a == 2 ? 0 : a + 1, cc = b == 2 ? 0 : b + 1;
+	const double s = 1.0 / w[a];
+	const double pc[3] = { 0.5 * (p0[0] + p1[0]), 0.5 * (p0[1] + p1[1]), 0.5 * (p0[2] + p1[2]) };
+	const double ph[3] = { 0.5 * (p1[0] - p0[0]), 0.5 * (p1[1] - p0[1]), 0.5 * (p1[2] - p0[2]) };
+	const double mc[3] = { (w[1] * pc[2] - w[2] * pc[1]) * s, (w[2] * pc[0] - w[0] * pc[2]) * s, (w[0] * pc[1] - w[1] * pc[0]) * s };
+	const double hv[3] = { (w[1] * ph[2] - w[2] * ph[1]) * s, (w[2] * ph[0] - w[0] * ph[2]) * s, (w[0] * ph[1] - w[1] * ph[0]) * s };
+	const float beta = (float)(w[b] * s), gamma = (float)(w[cc] * s);
+	const float mx = (float)mc[0], my = (float)mc[1], mz = (float)mc[2];
+	// H >= |h|_2 after every rounding: (1 + 2^-20) covers the double evaluation and the conversion to float
+	float H = (float)(sqrt(hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2]) * (1.0 + 0x1p-20));
+	// anything non-finite (degenerate triangle: len = 0; NaN or inf vertices; overflow of the moments): a record
+	// that always survives -- H = +inf makes x = -inf for every ray
+	const float chk = beta + gamma + mx + my + mz + H;
+	const bool ok = (chk - chk) == 0.0f;
+	q0 = ok ? make_float4(beta, gamma, mx, my) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	q1 = make_float4(ok ? mz : 0.0f, ok ? H : __builtin_inff(), __uint_as_float(idx), 0.0f);
+	return ok ? a : 0;
+}
+
+SP_DEV int cyl_class(const float* __restrict__ t) {
+	float4 q0, q1;
+	return cyl_record(t, 0u, q0, q1);
+}
+
+// ---- pass 1: triangles of each class in every block of 256
+__global__ void __launch_bounds__(256) k_cyl_count(const float* __restrict__ tris, uint32_t n, uint32_t* __restrict__ block_counts) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const int cls = i < n ? cyl_class(tris + (size_t)i * 12) : -1;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const int cnt = __syncthreads_count(cls == k);
+		if (threadIdx.x == 0) block_counts[(size_t)blockIdx.x * 3 + k] = (uint32_t)cnt;
+	}
+}
+
+// ---- pass 2 (one workgroup): exclusive prefix of the block counts per class; hdr[0..2] = class sizes,
+// hdr[3..5] = first tile of each class, hdr[6] = tiles in total
+__global__ void __launch_bounds__(256) k_cyl_offsets(uint32_t* __restrict__ block_counts, uint32_t nblocks, uint32_t* __restrict__ hdr) {
+	__shared__ uint32_t part[256];
+	__shared__ uint32_t total[3];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t per = (nblocks + 255u) / 256u;
+	const uint32_t lo = tid * per < nblocks ? tid * per : nblocks, hi = lo + per < nblocks ? lo + per : nblocks;
+	for (int k = 0; k < 3; ++k) {
+		uint32_t sum = 0;
+		for (uint32_t b = lo; b < hi; ++b) sum += block_counts[(size_t)b * 3 + k];
+		part[tid] = sum;
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t run = 0;
+			for (int j = 0; j < 256; ++j) { const uint32_t v = part[j]; part[j] = run; run += v; }
+			total[k] = run;
+		}
+		__syncthreads();
+		uint32_t run = part[tid];
+		for (uint32_t b = lo; b < hi; ++b) { const uint32_t v = block_counts[(size_t)b * 3 + k]; block_counts[(size_t)b * 3 + k] = run; run += v; }
+		__syncthreads();
+	}
+	if (tid == 0) {
+		uint32_t tile = 0;
+		for (int k = 0; k < 3; ++k) { hdr[k] = total[k]; hdr[3 + k] = tile; tile += (total[k] + kTile - 1u) / kTile; }
+		hdr[6] = tile;
+	}
+}
+
+// ---- pass 3: write every triangle's record to its place (stable within a class: ascending original index)
+__global__ void __launch_bounds__(256) k_cyl_scatter(const float* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ block_offsets,
+                                                    const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
+	__shared__ uint32_t wave_cnt[4][3];
+	const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid, wv = tid >> 6, lane = tid & 63u;
+	float4 q0, q1;
+	q0 = q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const int cls = i < n ? cyl_record(tris + (size_t)i * 12, i, q0, q1) : -1;
+	uint32_t rank = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const unsigned long long m = __ballot(cls == k);
+		if (cls == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		if (lane == 0) wave_cnt[wv][k] = (uint32_t)__popcll(m);
+	}
+	__syncthreads();
+	if (cls >= 0) {
+		for (uint32_t v = 0; v < wv; ++v) rank += wave_cnt[v][cls];
+		const size_t pos = (size_t)hdr[3 + cls] * kTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
+		rec[pos * 2 + 0] = q0;
+		rec[pos * 2 + 1] = q1;
+	}
+}
+
+// ---- pass 4: the ragged end of each class's last tile.  H = -inf: x = +inf, rejected by every ray that has a finite
+// margin; a ray whose filter is off (margin +inf) sends it to stage 2, where index n_tris is a zero exact record
+// (k_repack pads the exact stream), i.e. a = 0, rejected at geom.h:204
+__global__ void __launch_bounds__(256) k_cyl_pad(const uint32_t* __restrict__ hdr, uint32_t n_tris, float4* __restrict__ rec) {
+	const uint32_t k = blockIdx.x, tid = threadIdx.x;
+	const uint32_t n = hdr[k], first = hdr[3 + k] * kTile;
+	const uint32_t pos = n + tid;
+	if (pos < (n + kTile - 1u) / kTile * kTile) {
+		rec[((size_t)first + pos) * 2 + 0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		rec[((size_t)first + pos) * 2 + 1] = make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f);
+	}
+}
+
+// one 8 KB tile global -> LDS by LDS-DMA: 2 x 16 B per thread
+SP_DEV void cyl_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, uint32_t wbase) {
+	typedef __attribute__((address_space(1))) const void* gptr_t;
+	typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+		__builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + tid), (lptr_t)(dst + p * 256 + wbase), 16, 0, 0);
+}
+
+// x = |gm| - H*D for one (record, ray): 6 VALU
+SP_DEV float cyl_x(const float4 q0, const float4 q1, float Pa, float Pb, float Pc, float ndx, float ndy, float ndz, float D) {
+	float gm = __builtin_fmaf(q0.x, Pb, Pa);
+	gm = __builtin_fmaf(q0.y, Pc, gm);
+	gm = __builtin_fmaf(ndx, q0.z, gm);
+	gm = __builtin_fmaf(ndy, q0.w, gm);
+	gm = __builtin_fmaf(ndz, q1.x, gm);
+	return __builtin_fmaf(-q1.y, D, __builtin_fabsf(gm));
+}
+
+template <int R>
+struct CylRay {            // per-slot filter state
+	float Pa[R], Pb[R], Pc[R];     // ray moment pos x dir, rotated to the current class
+	float ndx[R], ndy[R], ndz[R];  // -dir
+	float D[R], Dq[R];             // |dir|_2 rounded up; margin (sp_filter_scan.h) a hair above, or +-inf
+};
+
+// Closest hit for the R rays of every lane.  Block-uniform call (barriers inside).
+template <int R>
+SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
+	__shared__ float4 sm[2 * kCylTileQ];
+	static_assert(R == 1 || R == 2 || R == 4, "bits per group must divide 32");
+	constexpr uint32_t kGPW = 32u / R;                 // groups of 4 triangles per 32-bit word
+	constexpr int kNW = (int)(64u / kGPW);             // words per tile
+	const uint32_t tid = threadIdx.x;
+	const uint32_t wbase = tid & ~63u;
+
+	CylRay<R> f;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const f3 P = cross3(s.o[r], s.dir[r]);
+		const float adx = fabsf(s.dir[r].x), ady = fabsf(s.dir[r].y), adz = fabsf(s.dir[r].z);
+		const float dn = adx + ady + adz;
+		const float on = fabsf(s.o[r].x) + fabsf(s.o[r].y) + fabsf(s.o[r].z);
+		const float dmax = fmaxf(adx, fmaxf(ady, adz));
+		// every product of stage 1 is bounded by mag (x sqrt(3) for the scaled w), a sum of six by 11 mag: below 1e37 nothing
+		// overflows.  |dir|^2 must neither overflow nor underflow: largest component in [1e-18, 1e18].  Outside (or NaN):
+		// the filter is off for this ray -- zero moment, margin +inf: every pair survives, no NaN can arise
+		const float mag = dn * (on + 2.0f * rv);
+		const bool fin = (mag < 1e37f) && (dmax > 1e-18f) && (dmax < 1e18f);
+		const bool on_ = fin && s.act[r];
+		f.Pa[r] = on_ ? P.x : 0.0f; f.Pb[r] = on_ ? P.y : 0.0f; f.Pc[r] = on_ ? P.z : 0.0f;
+		f.ndx[r] = on_ ? -s.dir[r].x : 0.0f; f.ndy[r] = on_ ? -s.dir[r].y : 0.0f; f.ndz[r] = on_ ? -s.dir[r].z : 0.0f;
+		f.D[r] = on_ ? __builtin_sqrtf(s.dir[r].x * s.dir[r].x + s.dir[r].y * s.dir[r].y + s.dir[r].z * s.dir[r].z) * (1.0f + 0x1p-21f) : 1.0f;
+		// survive <=> !(x > Dq); tested as sign(x - Dq') with Dq' a hair above Dq (and > 0), so that x == Dq survives too
+		const float dq = fmaxf(0x1p-16f * 1.01f * mag * (1.0f + 0x1p-20f), 1e-37f);
+		f.Dq[r] = !s.act[r] ? -__builtin_inff() : (fin ? dq : __builtin_inff());     // inactive slot: x - (-inf) = +inf, rejected
+		bd[r] = kMaxDist;
+		bi[r] = -1;
+	}
+
+	// the stream is one run of tiles: class 0's, then class 1's, then class 2's (each class starts on a tile boundary)
+	const uint32_t total_tiles = cs.hdr[6];
+	uint32_t cls = 0;
+	__syncthreads();                                  // readers of the previous scan are done with sm
+	cyl_tile_dma(cs.rec, sm, tid, wbase);
+	__syncthreads();                                  // (the barrier's fence waits for the DMA: vmcnt(0))
+	for (uint32_t gt = 0; gt < total_tiles; ++gt) {
+		// entering the next class: rotate the moment so that the class's dominant axis sits in Pa (wave-uniform)
+		while (cls < 2u && gt >= cs.hdr[4 + cls]) {
+#pragma unroll
+			for (int r = 0; r < R; ++r) { const float t0 = f.Pa[r]; f.Pa[r] = f.Pb[r]; f.Pb[r] = f.Pc[r]; f.Pc[r] = t0; }
+			++cls;
+		}
+		const float4* cur = sm + (gt & 1u) * kCylTileQ;
+		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kTile;
+		const uint32_t ngroups = ((left < (uint32_t)kTile ? left : (uint32_t)kTile) + 3u) / 4u;
+		// ---- stage 1: one bit per (group, slot); the first group ends up in the most significant bits
+		uint32_t word[kNW];
+		uint32_t g = 0;
+#pragma unroll
+		for (int wi = 0; wi < kNW; ++wi) {
+			uint32_t wv = 0;
+			const uint32_t gend = ngroups < (uint32_t)(wi + 1) * kGPW ? ngroups : (uint32_t)(wi + 1) * kGPW;
+			const uint32_t g0 = g;
+			for (; g < gend; ++g) {
+				float4 a0[4], a1[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { a0[u] = cur[g * 8u + 2 * u]; a1[u] = cur[g * 8u + 2 * u + 1]; }
+#pragma unroll
+				for (int r = 0; r < R; ++r) {
+					float x[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) x[u] = cyl_x(a0[u], a1[u], f.Pa[r], f.Pb[r], f.Pc[r], f.ndx[r], f.ndy[r], f.ndz[r], f.D[r]);
+					const float m = __builtin_fminf(__builtin_fminf(x[0], x[1]), __builtin_fminf(x[2], x[3]));
+					wv = __builtin_amdgcn_alignbit(wv, __float_as_uint(m - f.Dq[r]), 31);      // (wv << 1) | sign(m - Dq)
+				}
+			}
+			const uint32_t done = (g - g0) * R;                       // bits appended; left-align (wave-uniform shift)
+			word[wi] = done == 0u ? 0u : (wv << (32u - done));
+		}
+		// the next tile streams in while the survivors are resolved
+		if (gt + 1u < total_tiles) cyl_tile_dma(cs.rec + (size_t)(gt + 1u) * kCylTileQ, sm + ((gt + 1u) & 1u) * kCylTileQ, tid, wbase);
+		// ---- stage 2: every lane walks its set bits; one exact test per lane and round
+		uint32_t sub = 0;                                 // candidates of the current group already done (bit u)
+		for (;;) {
+			uint32_t any_w = 0;
+#pragma unroll
+			for (int wi = 0; wi < kNW; ++wi) any_w |= word[wi];
+			if (!__any(any_w != 0u)) break;
+			if (any_w != 0u) {
+				// first non-empty word, its first set bit
+				uint32_t wsel = word[kNW - 1], wid = kNW - 1;
+#pragma unroll
+				for (int wi = kNW - 2; wi >= 0; --wi) { const bool nz = word[wi] != 0u; wsel = nz ? word[wi] : wsel; wid = nz ? (uint32_t)wi : wid; }
+				const uint32_t e = (uint32_t)__builtin_clz(wsel);             // entry within the word
+				const uint32_t grp = wid * kGPW + e / R;
+				const int slot = (int)(e % R);
+				float Pa = f.Pa[0], Pb = f.Pb[0], Pc = f.Pc[0], ndx = f.ndx[0], ndy = f.ndy[0], ndz = f.ndz[0], D = f.D[0], Dq = f.Dq[0];
+				float ox = s.o[0].x, oy = s.o[0].y, oz = s.o[0].z;
+				float dx = s.dir[0].x, dy = s.dir[0].y, dz = s.dir[0].z;
+				int src = s.src[0];
+				float best = bd[0]; int besti = bi[0];
+#pragma unroll
+				for (int r = 1; r < R; ++r) {
+					const bool pick = (slot == r);
+					Pa = pick ? f.Pa[r] : Pa; Pb = pick ? f.Pb[r] : Pb; Pc = pick ? f.Pc[r] : Pc;
+					ndx = pick ? f.ndx[r] : ndx; ndy = pick ? f.ndy[r] : ndy; ndz = pick ? f.ndz[r] : ndz;
+					D = pick ? f.D[r] : D; Dq = pick ? f.Dq[r] : Dq;
+					ox = pick ? s.o[r].x : ox; oy = pick ? s.o[r].y : oy; oz = pick ? s.o[r].z : oz;
+					dx = pick ? s.dir[r].x : dx; dy = pick ? s.dir[r].y : dy; dz = pick ? s.dir[r].z : dz;
+					src = pick ? s.src[r] : src;
+					best = pick ? bd[r] : best; besti = pick ? bi[r] : besti;
+				}
+				// the group's four records (per-lane LDS address) and their x again; the first survivor not yet done
+				uint32_t cand = 0; int idx = 0;
+#pragma unroll
+				for (int u = 3; u >= 0; --u) {
+					const float4 q0 = cur[grp * 8u + 2 * u], q1 = cur[grp * 8u + 2 * u + 1];
+					const float x = cyl_x(q0, q1, Pa, Pb, Pc, ndx, ndy, ndz, D);
+					const bool sv = !(x - Dq >= 0.0f) && !((sub >> u) & 1u);      // the sign-bit decision again; NaN -> survivor
+					cand = sv ? (cand | (1u << u)) : cand;
+					idx = sv ? (int)__float_as_uint(q1.z) : idx;               // ends as the lowest surviving u's index
+				}
+				const uint32_t lowest = cand & (0u - cand);
+				const bool last = (cand == lowest);                             // no further survivor in this group
+				sub = last ? 0u : (sub | lowest);
+				const uint32_t clear = last ? ~(0x80000000u >> e) : 0xffffffffu;
+#pragma unroll
+				for (int wi = 0; wi < kNW; ++wi) word[wi] = (wid == (uint32_t)wi) ? (word[wi] & clear) : word[wi];
+				if (cand != 0u) {
+					const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
+					const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+					// ascending-index scan with "first strictly smaller d wins" (cpu_renderer.cpp:44) == lexicographic (d, index) minimum
+					const bool take = (d > 0.0f) && (idx != src) && ((d < best) || (d == best && idx < besti));
+					best = take ? d : best;
+					besti = take ? idx : besti;
+#pragma unroll
+					for (int r = 0; r < R; ++r) { const bool pick = (slot == r); bd[r] = pick ? best : bd[r]; bi[r] = pick ? besti : bi[r]; }
+				}
+			}
+		}
+		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
+	}
+}
+
+} // namespace sp

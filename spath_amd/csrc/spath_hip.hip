@@ -7,6 +7,8 @@
 #include "spath_hip.h"
 #include "sp_kernels.h"
 #include "sp_filter_scan.h"
+#include "sp_cyl_scan.h"
+#include "sp_scan_kernels.h"
 #include "sp_bvh.h"
 
 #include <hip/hip_runtime.h>
@@ -34,7 +36,7 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, cyl_rec, cyl_cnt, cyl_hdr;
 	bool bvh_valid = false;
 	uint32_t bvh_leaves = 0, bvh_big = 0;
 	size_t n_tris = 0;
@@ -74,30 +76,41 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 	return SPHIP_OK;
 }
 
-constexpr int kNumVariants = 7;       // selectable brute-force scan kernels; 8 = the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
-constexpr int kVariantAccel = 8;
+// kernel variants selectable through the low byte of `flags` (sphip_kernel_name); all brute force except 8
+constexpr int kVariantAccel = 8;          // the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
+constexpr int kVariantLast = 13;
 constexpr uint64_t kChunkTargetBlocks = 262144;         // 256 x the 1024 resident workgroups (measured: profiles/r01_sample_chunks.log)
 constexpr uint64_t kChunkMaxBytes = 16ull << 30;         // cap of the per-sample scratch buffer
-const char* const kVariantNames[kVariantAccel + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
-                                                      "accel_lbvh" };
+const char* const kVariantNames[kVariantLast + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
+                                                      "accel_lbvh", "rpl_cyl1", "rpl_cyl2", "rpl_cyl4", "rpl_cyl2s", "rpl_cyl4s" };
+
+// the two-stage scan variants: paths per lane (R), whether the R paths are consecutive samples of ONE pixel (split) or R
+// pixels, and the scan generation (0 = slab filter + LDS queues, sp_filter_scan.h; 1 = cylinder filter + bit words, sp_cyl_scan.h)
+struct TwoStage { int R; bool split; int scan; };
+bool two_stage(int variant, TwoStage* out) {
+	static const TwoStage tab[kVariantLast + 1] = { {0, false, 0}, {0, false, 0}, {0, false, 0}, {2, false, 0}, {4, false, 0}, {1, false, 0}, {2, true, 0}, {4, true, 0},
+	                                                {0, false, 0}, {1, false, 1}, {2, false, 1}, {4, false, 1}, {2, true, 1}, {4, true, 1} };
+	if (variant < 0 || variant > kVariantLast || tab[variant].R == 0) return false;
+	if (out) *out = tab[variant];
+	return true;
+}
 
 int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_samples) {
 	if (flags & SPHIP_FLAG_ACCEL) return kVariantAccel;
 	const int v = flags & SPHIP_KERNEL_MASK;
-	if (v >= 1 && v <= kNumVariants) return v;
+	if (v >= 1 && v <= kVariantLast) return v;
 	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
-	// Path tracing with >= 2 spp: two consecutive SAMPLES of a pixel per lane (rpl_filter2s).  It halves the LDS reads
-	// per test like two pixels per lane do and keeps 256 pixels per workgroup; with sample chunks (launch_render) every
-	// filter variant gets enough workgroups and all run at the same VALU-bound rate, this one never slower
-	// (profiles/r01_shard_speed.log, r01_sample_chunks.log).  One scan per ray (flat pass, 1 spp): two pixels per lane
-	// when that still leaves >= ~768 workgroups, else one.
-	if (mode == SPHIP_MODE_PT && n_samples >= 2) return 6;
-	return n_rays >= 384u * 1024u ? 3 : 5;
+	// Path tracing with >= 2 spp: consecutive SAMPLES of a pixel share a lane (a record read from LDS serves all of them; a
+	// workgroup still covers 256 pixels, and sample chunks (launch_render) supply the workgroups a small frame lacks).
+	// One scan per ray (flat pass, 1 spp): pixels share a lane when that still leaves >= ~768 workgroups.
+	if (mode == SPHIP_MODE_PT && n_samples >= 4) return 13;
+	if (mode == SPHIP_MODE_PT && n_samples >= 2) return 12;
+	return n_rays >= 768u * 1024u ? 11 : (n_rays >= 384u * 1024u ? 10 : 9);
 }
 
 int repack(sphip_ctx* c, hipStream_t st) {
 	const uint32_t n = (uint32_t)c->n_tris;
-	const uint32_t n_pad = (n + sp::kTile - 1) / sp::kTile * sp::kTile;      // whole LDS tiles, zero records behind n
+	const uint32_t n_pad = (n / sp::kTile + 1) * sp::kTile;      // whole LDS tiles and at least one zero record behind n (index n: the padding of sp_cyl_scan.h points at it)
 	int rc = ensure(c, c->scan, (size_t)n_pad * 48);
 	if (rc) return rc;
 	hipLaunchKernelGGL(sp::k_repack, dim3((n_pad + 255) / 256), dim3(256), 0, st,
@@ -109,6 +122,18 @@ int repack(sphip_ctx* c, hipStream_t st) {
 	hipLaunchKernelGGL(sp::k_repack_filter, dim3((n_pad + 255) / 256), dim3(256), 0, st,
 	                   (const float*)c->tris.p, (float4*)c->filt.p, (unsigned int*)c->bounds.p, n, n_pad);
 	HIP_TRY(c, hipGetLastError());
+	// class-sorted cylinder records (sp_cyl_scan.h): count per block -> offsets -> scatter -> pad, all on the device
+	{
+		const uint32_t nblocks = (n + 255) / 256;
+		if ((rc = ensure(c, c->cyl_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cyl_hdr, 256)) ||
+		    (rc = ensure(c, c->cyl_rec, ((size_t)nblocks + 3) * sp::kTile * 32))) return rc;
+		hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cyl_cnt.p);
+		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cyl_cnt.p, nblocks, (uint32_t*)c->cyl_hdr.p);
+		hipLaunchKernelGGL(sp::k_cyl_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cyl_cnt.p,
+		                   (const uint32_t*)c->cyl_hdr.p, (float4*)c->cyl_rec.p);
+		hipLaunchKernelGGL(sp::k_cyl_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)c->cyl_hdr.p, n, (float4*)c->cyl_rec.p);
+		HIP_TRY(c, hipGetLastError());
+	}
 	c->have_scene = true;
 	c->bvh_valid = false;
 	return SPHIP_OK;
@@ -257,10 +282,13 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	// many ends with a long tail (its time is that of the slowest workgroup, ~12 % above the mean when everything starts
 	// together), so small frames and multi-GPU shards are split along the samples as well
 	uint32_t chunks = 1;
-	if (mode == SPHIP_MODE_PT && variant >= 3 && variant != kVariantAccel) {
-		const uint32_t rays_per_block = variant == 3 ? 512u : variant == 4 ? 1024u : 256u;
+	TwoStage ts{1, false, 0};
+	const bool is_ts = two_stage(variant, &ts);
+	const uint32_t slots = is_ts && ts.split ? (uint32_t)ts.R : 1u;                       // samples of one pixel per lane
+	const uint32_t rays_per_block = is_ts && !ts.split ? 256u * (uint32_t)ts.R : 256u;
+	if (mode == SPHIP_MODE_PT && is_ts) {
 		const uint64_t px_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
-		const uint64_t n_iter = variant == 7 ? (n_samples + 3) / 4 : variant == 6 ? (n_samples + 1) / 2 : n_samples;
+		const uint64_t n_iter = (n_samples + slots - 1) / slots;
 		const uint32_t forced = ((uint32_t)flags & SPHIP_FLAG_CHUNKS_MASK) >> SPHIP_FLAG_CHUNKS_SHIFT;
 		if (forced) chunks = forced;
 		else while (px_blocks * chunks < kChunkTargetBlocks && chunks < 128) chunks *= 2;
@@ -271,7 +299,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 			// Keep the scratch under the cap and under 90 % of what the device has free beyond the cached buffers.
 			size_t free_b = 0, total_b = 0;
 			if (samp_bytes > kChunkMaxBytes || hipMemGetInfo(&free_b, &total_b) != hipSuccess) chunks = 1;
-			const uint64_t lanes = (uint64_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u);
+			const uint64_t lanes = (uint64_t)((n_rays + 1023) / 1024 * 1024) * slots;
 			while (chunks > 1) {
 				const uint64_t work_bytes = lanes * chunks * 52;
 				const uint64_t need = (samp_bytes > c->samp.cap ? samp_bytes : 0) + (work_bytes > c->work.cap ? work_bytes : 0);
@@ -285,20 +313,27 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 			a.samp = (float*)c->samp.p;
 		}
 	}
-	const dim3 grid((unsigned)((n_rays + 255) / 256 * chunks)), block(256);
-	const dim3 grid2((unsigned)((n_rays + 511) / 512 * chunks)), grid4((unsigned)((n_rays + 1023) / 1024 * chunks));
-	// path-history / accumulator work buffer of the filter kernels: 5 x int2 + 3 x float per (padded) ray and chunk
-	const uint64_t n_work64 = (uint64_t)((n_rays + 1023) / 1024 * 1024) * (variant == 7 ? 4u : variant == 6 ? 2u : 1u) * chunks;
-	if (mode == SPHIP_MODE_PT && variant >= 3 && n_work64 > 0xffffffffull)
+	const dim3 block(256);
+	const dim3 grid((unsigned)((n_rays + 255) / 256 * chunks));                           // exact-only kernels, accel, split variants, R = 1
+	// one-scan modes (flat pass, hits) have no samples to share a lane: a split variant runs there with R pixels per lane
+	const uint32_t rpb1 = is_ts ? 256u * (uint32_t)ts.R : 256u;
+	const dim3 grid_px((unsigned)((n_rays + rpb1 - 1) / rpb1));
+	const dim3 grid_pt((unsigned)((n_rays + rays_per_block - 1) / rays_per_block * chunks));
+	// path-history / accumulator work buffer of the two-stage kernels: 5 x int2 + 3 x float per (padded) path and chunk
+	const uint64_t n_work64 = (uint64_t)((n_rays + 1023) / 1024 * 1024) * slots * chunks;
+	if (mode == SPHIP_MODE_PT && is_ts && n_work64 > 0xffffffffull)
 		return fail(c, SPHIP_E_INVALID, "n_rays %zu too large for one launch of this kernel variant; shard the frame", n_rays);
 	const uint32_t n_work = (uint32_t)n_work64;
 	int2* hist = nullptr; float* acc = nullptr;
-	if (mode == SPHIP_MODE_PT && variant >= 3) {
+	if (mode == SPHIP_MODE_PT && is_ts) {
 		if ((rc = ensure(c, c->work, (size_t)n_work * 52))) return rc;
 		hist = (int2*)c->work.p;
 		acc = (float*)((char*)c->work.p + (size_t)n_work * 40);
 	}
-	const float4* filt = (const float4*)c->filt.p;
+	sp::ScanSrc src2{};
+	src2.filt = (const float4*)c->filt.p;
+	src2.cyl.rec = (const float4*)c->cyl_rec.p;
+	src2.cyl.hdr = (const uint32_t*)c->cyl_hdr.p;
 	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
 	sp::BvhArgs B{};
 	if (variant == kVariantAccel) {
@@ -313,23 +348,35 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		else                              hipLaunchKernelGGL(sp::k_accel<1>, grid, block, 0, st, a, B, nullptr, nullptr, nullptr);
 	} else if (mode == kModeHits) {
 		int* oi = (int*)d_rgba; float* od = (float*)d_accum;
-		if (variant >= 5)      hipLaunchKernelGGL(sp::k_hit_filter<1>, grid, block, 0, st, a, filt, bnd, d_src, oi, od);
-		else if (variant == 4) hipLaunchKernelGGL(sp::k_hit_filter<4>, grid4, block, 0, st, a, filt, bnd, d_src, oi, od);
-		else if (variant == 3) hipLaunchKernelGGL(sp::k_hit_filter<2>, grid2, block, 0, st, a, filt, bnd, d_src, oi, od);
+		if (is_ts) {
+#define SP_HIT(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd, d_src, oi, od)
+			if (ts.scan == 0) { if (ts.R == 4) SP_HIT(4, 0); else if (ts.R == 2) SP_HIT(2, 0); else SP_HIT(1, 0); }
+			else              { if (ts.R == 4) SP_HIT(4, 1); else if (ts.R == 2) SP_HIT(2, 1); else SP_HIT(1, 1); }
+#undef SP_HIT
+		}
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_hit<2>, grid, block, 0, st, a, d_src, oi, od);
 		else                   hipLaunchKernelGGL(sp::k_hit<1>, grid, block, 0, st, a, d_src, oi, od);
 	} else if (mode == SPHIP_MODE_FLAT) {
-		if (variant >= 5)      hipLaunchKernelGGL(sp::k_flat_filter<1>, grid, block, 0, st, a, filt, bnd);
-		else if (variant == 4) hipLaunchKernelGGL(sp::k_flat_filter<4>, grid4, block, 0, st, a, filt, bnd);
-		else if (variant == 3) hipLaunchKernelGGL(sp::k_flat_filter<2>, grid2, block, 0, st, a, filt, bnd);
+		if (is_ts) {
+#define SP_FLAT(R_, S_) hipLaunchKernelGGL((sp::k_flat_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd)
+			if (ts.scan == 0) { if (ts.R == 4) SP_FLAT(4, 0); else if (ts.R == 2) SP_FLAT(2, 0); else SP_FLAT(1, 0); }
+			else              { if (ts.R == 4) SP_FLAT(4, 1); else if (ts.R == 2) SP_FLAT(2, 1); else SP_FLAT(1, 1); }
+#undef SP_FLAT
+		}
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_flat<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
 	} else {
-		if (variant == 7)      hipLaunchKernelGGL((sp::k_pt_filter<4, true>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
-		else if (variant == 6) hipLaunchKernelGGL((sp::k_pt_filter<2, true>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
-		else if (variant == 5) hipLaunchKernelGGL((sp::k_pt_filter<1, false>), grid, block, 0, st, a, filt, bnd, hist, acc, n_work);
-		else if (variant == 4) hipLaunchKernelGGL((sp::k_pt_filter<4, false>), grid4, block, 0, st, a, filt, bnd, hist, acc, n_work);
-		else if (variant == 3) hipLaunchKernelGGL((sp::k_pt_filter<2, false>), grid2, block, 0, st, a, filt, bnd, hist, acc, n_work);
+		if (is_ts) {
+#define SP_PT(R_, SPLIT_, S_) hipLaunchKernelGGL((sp::k_pt_filter<R_, SPLIT_, S_>), grid_pt, block, 0, st, a, src2, bnd, hist, acc, n_work)
+			if (ts.scan == 0) {
+				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 0); else SP_PT(2, true, 0); }
+				else          { if (ts.R == 4) SP_PT(4, false, 0); else if (ts.R == 2) SP_PT(2, false, 0); else SP_PT(1, false, 0); }
+			} else {
+				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 1); else SP_PT(2, true, 1); }
+				else          { if (ts.R == 4) SP_PT(4, false, 1); else if (ts.R == 2) SP_PT(2, false, 1); else SP_PT(1, false, 1); }
+			}
+#undef SP_PT
+		}
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_pt<2>, grid, block, 0, st, a);
 		else                   hipLaunchKernelGGL(sp::k_pt<1>, grid, block, 0, st, a);
 	}
@@ -352,7 +399,7 @@ extern "C" {
 int sphip_abi_version(void) { return SPHIP_ABI_VERSION; }
 
 const char* sphip_kernel_name(int variant) {
-	if (variant < 0 || variant > kVariantAccel) return nullptr;
+	if (variant < 0 || variant > kVariantLast) return nullptr;
 	return kVariantNames[variant];
 }
 
@@ -393,8 +440,8 @@ void sphip_destroy(sphip_t* c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[14] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
-	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx };
+	DevBuf* bufs[17] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
