@@ -266,6 +266,11 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 		}
 		// the next tile streams in while the survivors are resolved
 		if (gt + 1u < total_tiles) cyl_tile_dma(cs.rec + (size_t)(gt + 1u) * kCylTileQ, sm + ((gt + 1u) & 1u) * kCylTileQ, tid, wbase);
+#ifdef SP_FILTER_STATS
+		uint32_t st_bits = 0, st_rounds = 0, st_exact = 0;      // experiment build only -> a.scans[1..4]
+#pragma unroll
+		for (int wi = 0; wi < kNW; ++wi) st_bits += (uint32_t)__builtin_popcount(word[wi]);
+#endif
 		// ---- stage 2: every lane walks its set bits; one exact test per lane and round
 		uint32_t sub = 0;                                 // candidates of the current group already done (bit u)
 		for (;;) {
@@ -273,6 +278,9 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 #pragma unroll
 			for (int wi = 0; wi < kNW; ++wi) any_w |= word[wi];
 			if (!__any(any_w != 0u)) break;
+#ifdef SP_FILTER_STATS
+			++st_rounds;
+#endif
 			if (any_w != 0u) {
 				// first non-empty word, its first set bit
 				uint32_t wsel = word[kNW - 1], wid = kNW - 1;
@@ -314,6 +322,9 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 #pragma unroll
 				for (int wi = 0; wi < kNW; ++wi) word[wi] = (wid == (uint32_t)wi) ? (word[wi] & clear) : word[wi];
 				if (cand != 0u) {
+#ifdef SP_FILTER_STATS
+					++st_exact;
+#endif
 					const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
 					const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
 					// ascending-index scan with "first strictly smaller d wins" (cpu_renderer.cpp:44) == lexicographic (d, index) minimum
@@ -325,6 +336,13 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 				}
 			}
 		}
+#ifdef SP_FILTER_STATS
+		{
+			uint32_t v = st_bits, x = st_exact;
+			for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); x += __shfl_xor(x, off, 64); }
+			if ((tid & 63u) == 0) { atomicAdd(a.scans + 1, (unsigned long long)v); atomicAdd(a.scans + 2, (unsigned long long)st_rounds); atomicAdd(a.scans + 3, 1ull); atomicAdd(a.scans + 4, (unsigned long long)x); }
+		}
+#endif
 		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
 	}
 }

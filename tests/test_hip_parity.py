@@ -19,7 +19,9 @@ from spath_amd.dist import RowTilePlan, ShardedRenderer
 pytestmark = pytest.mark.gpu
 
 ACCUM_LINF_TOLERANCE = 0.0          # float accumulators: exact
-VARIANTS = [1, 2, 3, 4, 5, 6, 7]    # rpl_sload, rpl_lds, rpl_filter2, rpl_filter4, rpl_filter1, rpl_filter2s, rpl_filter4s
+# rpl_sload, rpl_lds; slab-filter scans rpl_filter2/4/1/2s/4s; cylinder-filter scans rpl_cyl1/2/4/2s/4s (8 is the opt-in acceleration structure)
+VARIANTS = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13]
+TWO_STAGE = [3, 4, 5, 6, 7, 9, 10, 11, 12, 13]
 
 
 def dev(a):
@@ -228,7 +230,7 @@ def test_primary_reuse_same_image_fewer_scans(hip, O):
         assert b_st["scans_executed"] <= c_st["scans_executed"] <= a_st["scans_executed"]
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", TWO_STAGE)
 def test_sample_chunks_do_not_change_a_bit(hip, O, variant):
     """A launch split into (pixel, sample chunk) lanes + the in-order resolve pass == the unsplit launch == the oracle."""
     t, m = scene.closed_room(400)
