@@ -5,19 +5,26 @@ A step = one full render (renderer::render semantics, reference src/cpu_renderer
 BASELINE.json configs[2]: closed-room scene with 10,000 triangles, 1920x1080, 256 spp, 5 bounces,
 all inputs (rays, triangles, materials) resident in HBM before the timed region.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W
+N > 1 without a torch.distributed environment: this process starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py`, before anything touches
+the GPU) and relays rank 0's JSON line; started under torch.distributed.run it is a rank.
 
 N > 1: the same image is split into pixel-row tiles dealt round-robin to the ranks (strong
 scaling; spath_amd/dist.py); each step ends with one RCCL gather of the RGBA8 tiles to rank 0.
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus `roofline` and
 `cpu_baseline`:
-  roofline.achieved = scans_executed x n_tris x 48 B / kernel time  (algorithmic bytes the
-  reference's scan reads per ray, sizeof(geom::triangle), geom.h:185-190), kernel time from HIP
-  events on the launch stream.  It is an *effective* bandwidth: LDS/L2 reuse lets it exceed the
-  HBM peak, which is why valu_frac (52 flop per ray-triangle test against the 157.3 TFLOP/s
-  FP32 vector peak) is printed next to it.
+  roofline            the BINDING roof of the dominant kernel: FP32 vector (VALU) instruction issue.
+                      achieved = executed lane-instructions per second = ray-triangle tests/s x lane-instructions
+                      per test, the latter from a committed rocprofv3 PMC pass of this very command
+                      (profiles/valu_issue.json <- tools/valu_issue_from_pmc.py <- SQ_INSTS_VALU);
+                      peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md).  frac <= 1.
+  roofline.hbm_effective   the accounting SURVEY.md 8(d) / the north_star name: scans x n_tris x 48 B
+                      (sizeof(geom::triangle), what the reference's scan reads per ray) / kernel time against the
+                      8 TB/s HBM peak.  It is an EFFECTIVE bandwidth and exceeds 1: every triangle fetched into LDS
+                      serves 1024 rays, the 320 KB record stream lives in L2; `traffic` is what HBM really moved.
+Kernel time = HIP events on the launch stream around every step's kernels.
 """
 from __future__ import annotations
 
@@ -32,8 +39,85 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+VALU_PEAK_TINSTR = 256 * 4 * 32 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.64 T lane-instructions/s
 BYTES_PER_TEST = 48          # sizeof(geom::triangle)
 FLOPS_PER_TEST = 52
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` with no torch.distributed environment: start the N ranks as children of this
+    process (which never touches the GPU), pass rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    other = [l for l in p.stdout.splitlines() if l.strip() and not l.startswith("{")]
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if p.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank launch failed (rc {p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+class ClockSampler:
+    """Shader clock while the timed steps run, from the driver's pp_dpm_sclk table (the '*' row), every 0.25 s.
+    The guide's caveat applies: sysfs may read a few % above the in-kernel clock; this is context for the roofline."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.paths = []
+        if pci_bus_id:                    # the device this rank renders on, e.g. 0000:75:00.0
+            self.paths = glob.glob(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/pp_dpm_sclk")
+        self.samples, self._stop, self._t = [], False, None
+
+    def _read(self, path):
+        try:
+            for line in open(path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+        except Exception:
+            return None
+        return None
+
+    def start(self):
+        import threading
+        if not self.paths:
+            return
+        path = self.paths[0]
+
+        def loop():
+            while not self._stop:
+                v = self._read(path)
+                if v:
+                    self.samples.append(v)
+                time.sleep(0.25)
+        self._t = threading.Thread(target=loop, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+        return (sum(self.samples) / len(self.samples)) if self.samples else None
+
+
+def profile_entry(fname, key):
+    """Figures that only a profiler pass can supply (PMC counters, the statistics build), committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
 
 
 def host_cores() -> int:
@@ -103,16 +187,19 @@ def main():
     ap.add_argument("--extras", action="store_true", help="after the timed region also run (untimed, reduced spp) the exact-only scan, "
                     "primary-hit reuse and the opt-in acceleration structure, and report them under reference_runs_untimed; "
                     "off by default so that a profile of the default command contains only the timed kernel")
+    ap.add_argument("--no-worst-case", action="store_true", help="skip the (untimed) large-triangle scene figure")
     ap.add_argument("--cpu-w", type=int, default=192)
     ap.add_argument("--cpu-h", type=int, default=108)
     ap.add_argument("--cpu-spp", type=int, default=16)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from spath_amd import capi, scene, view
-    from spath_amd.dist import RowTilePlan, ShardedRenderer, balanced_tile_rows, gather_to_root
+    from spath_amd.dist import Gatherer, RowTilePlan, ShardedRenderer, balanced_tile_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -153,6 +240,7 @@ def main():
     d_tris, d_mats = torch.from_numpy(tris).to(dev), torch.from_numpy(mats).to(dev)
     ctx.set_scene_device(d_tris.data_ptr(), d_mats.data_ptr(), NT, stream)
     shard = ShardedRenderer(ctx, plan, rank, rays, dev)
+    gather = Gatherer(plan, rank)
     torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -166,7 +254,7 @@ def main():
         if i_timed is not None:
             ev[i_timed][1].record()
         if world > 1:
-            image = gather_to_root(local.cpu() if rehearsal else local, plan, rank)
+            image = gather(local.cpu() if rehearsal else local)
         else:
             image = local
 
@@ -179,11 +267,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    bus = None
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:
+        bus = None
+    clock = ClockSampler(bus)
+    if rank == 0:
+        clock.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    sclk_mhz = clock.stop() if rank == 0 else None
+    # per-channel sums of the assembled RGBA8 frame (identical for every --gpus N: pixel-keyed RNG); taken now, the untimed
+    # runs below reuse the shard's output buffer
+    image_sum = [int(x) for x in image[:, :3].to(torch.int64).sum(dim=0).tolist()] if rank == 0 else None
     st = ctx.stats()                       # figures of the last launch on this rank
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     # outside the timed region, for reference: the exact-only scan (every pair through the full Moeller-Trumbore test,
@@ -218,6 +319,26 @@ def main():
         torch.cuda.synchronize()
         exact_only["with_accel_structure_opt_in"] = {"spp": spp_r, "kernel_ms": round(e0.elapsed_time(e1), 3),
                                                      "nominal_Mray_per_s": round(W * H * spp_r * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2)}
+    worst = None
+    if world == 1 and NT >= 64 and not args.no_worst_case:
+        # large triangles (clutter x10: most rays cross most cylinders): how far the two-stage scan degrades.  Untimed, after
+        # the timed region, with the 2-samples-per-lane instantiation so that the headline kernel's profile stays unmixed
+        wt, wm = scene.closed_room(NT, clutter_scale=10.0)
+        d_wt, d_wm = torch.from_numpy(wt).to(dev), torch.from_numpy(wm).to(dev)
+        ctx.set_scene_device(d_wt.data_ptr(), d_wm.data_ptr(), NT, stream)
+        spp_w = min(SPP, 4)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        shard.render(spp_w, seed=1, mode=capi.MODE_PT, flags=variants["rpl_cyl2s"], stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        sw = ctx.stats()
+        worst = {"scene": f"closed_room({NT}, clutter_scale=10): clutter triangles 10x larger", "kernel": "rpl_cyl2s", "spp": spp_w,
+                 "kernel_ms": round(e0.elapsed_time(e1), 3), "Mray_per_s": round(W * H * spp_w * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2),
+                 "tests_per_s": round(sw["scans_executed"] * NT / (e0.elapsed_time(e1) * 1e-3), 1),
+                 "note": "no survivor queue, hence no overflow path: degrades smoothly towards the exact-only scan"}
+        ctx.set_scene_device(d_tris.data_ptr(), d_mats.data_ptr(), NT, stream)
+        torch.cuda.synchronize()
     if world > 1:
         cdev = torch.device("cpu") if rehearsal else dev
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -226,9 +347,11 @@ def main():
         s = torch.tensor([float(st["scans_executed"]), max(kernel_ms) if kernel_ms else 0.0], dtype=torch.float64, device=cdev)
         s_sum = s.clone(); dist.all_reduce(s_sum, op=dist.ReduceOp.SUM)
         s_max = s.clone(); dist.all_reduce(s_max, op=dist.ReduceOp.MAX)
-        scans_per_step, kern_ms_max = float(s_sum[0].item()), float(s_max[1].item())
+        s_min = s.clone(); dist.all_reduce(s_min, op=dist.ReduceOp.MIN)
+        scans_per_step, kern_ms_max, kern_ms_min = float(s_sum[0].item()), float(s_max[1].item()), float(s_min[1].item())
     else:
-        scans_per_step, kern_ms_max = float(st["scans_executed"]), (sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0)
+        scans_per_step = float(st["scans_executed"])
+        kern_ms_max = kern_ms_min = (sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0)
 
     if rank == 0:
         nominal = W * H * SPP * 5
@@ -238,15 +361,15 @@ def main():
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms) * 1e-3) if kernel_ms else float("nan")
         my_scans = float(st["scans_executed"])
         achieved = my_scans * NT * BYTES_PER_TEST / avg_kernel_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"{NT}tris_{W}x{H}x{SPP}_g{world}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kname = capi.load().sphip_kernel_name(st["kernel_variant"]).decode()
+        key = f"{NT}tris_{W}x{H}x{SPP}_g{world}_{kname}"
+        tr = profile_entry("hbm_traffic.json", key) or {}
+        traffic = tr.get("hbm_bytes_per_launch")
+        vi = profile_entry("valu_issue.json", key) or {}
+        fs = profile_entry("filter_stats.json", f"{NT}tris_{W}x{H}_{kname}") or {}
+        tests_per_s = my_scans * NT / avg_kernel_s
+        lane_instr = vi.get("lane_instr_per_test")
+        valu_achieved = tests_per_s * lane_instr / 1e12 if lane_instr else None
         out = {
             "metric": "Mray/s (primary x spp x bounces)",
             "value": round(value, 3),
@@ -270,23 +393,37 @@ def main():
                 "arithmetic": "strict (no FMA contraction, IEEE divide): bit-identical to the CPU oracle",
             },
             "scans_per_step": scans_per_step,
-            # per-channel sums of the assembled RGBA8 frame: identical for every --gpus N (pixel-keyed RNG)
-            "image_sum_rgb": [int(x) for x in image[:, :3].to(torch.int64).sum(dim=0).tolist()],
+            "image_sum_rgb": image_sum,
             "nominal_rays_per_step": nominal,
             "reference_runs_untimed": exact_only,
+            "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+            "kernel_ms_per_rank": {"min": round(kern_ms_min, 3), "max": round(kern_ms_max, 3)},
+            "worst_case_untimed": worst,
             "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # the binding roof: FP32 vector instruction issue (no MFMA on this path; HBM is idle, see `traffic`)
+                "bound": "valu",
+                "achieved": round(valu_achieved, 3) if valu_achieved else None,
+                "peak": round(VALU_PEAK_TINSTR, 3),
+                "unit": "Tinstr/s",
+                "frac": round(valu_achieved / VALU_PEAK_TINSTR, 4) if valu_achieved else None,
                 "traffic": traffic,
-                "kernel": "k_pt_filter<R>" if st["kernel_variant"] >= 3 else "k_pt<variant>",
+                "kernel": "k_pt_filter<R, SPLIT, SCAN> (" + kname + ")" if st["kernel_variant"] >= 3 else "k_pt<variant>",
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
-                "algorithmic_bytes_per_launch": my_scans * NT * BYTES_PER_TEST,
-                "note": "effective (logical-stream) bandwidth of rank 0's launch; exceeds HBM peak because triangles are reused from LDS/L2",
-                "tests_per_s": round(my_scans * NT / avg_kernel_s, 1),
-                "valu_frac": round(my_scans * NT * FLOPS_PER_TEST / avg_kernel_s / (FP32_PEAK_TFLOPS * 1e12), 4),
+                "tests_per_s": round(tests_per_s, 1),
+                "lane_instr_per_test": lane_instr,
+                "lane_instr_source": vi.get("source", "no PMC pass committed for this configuration and kernel: valu fraction unavailable"),
+                "peak_definition": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md); one wave64 VALU instruction = 2 issue cycles",
+                "sclk_observed_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
+                "frac_at_observed_sclk": round(valu_achieved / (256 * 4 * 32 * sclk_mhz * 1e6 / 1e12), 4) if (valu_achieved and sclk_mhz) else None,
+                "filter": {"pairs_surviving_stage1": fs.get("survivor_frac"), "stage2_rounds_per_tile": fs.get("rounds_per_tile"),
+                           "stage2_lane_utilisation": fs.get("lane_utilisation"), "queue_overflows": 0 if st["kernel_variant"] >= 9 else fs.get("overflows"),
+                           "source": fs.get("source")},
+                # the north_star's accounting: logical triangle-stream bandwidth against the HBM peak (exceeds 1 by design)
+                "hbm_effective": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes_per_launch": my_scans * NT * BYTES_PER_TEST,
+                                  "note": "effective (logical-stream) bandwidth of rank 0's launch; exceeds the HBM peak because a record fetched "
+                                          "into LDS serves every ray of the workgroup and the stream lives in L2; HBM really moved `traffic` bytes"},
+                "algorithmic_flop_frac": round(my_scans * NT * FLOPS_PER_TEST / avg_kernel_s / (FP32_PEAK_TFLOPS * 1e12), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,7 @@ class RowTilePlan:
         self.tile_px = tile_rows * width
         self.n_tiles = -(-height // tile_rows)
         self.npix = width * height
+        self._ids = {}            # (rank, device) -> global pixel ids as a torch tensor, built once
 
     def tiles_of(self, rank: int):
         return list(range(rank, self.n_tiles, self.g))
@@ -53,36 +54,60 @@ class RowTilePlan:
                for t in self.tiles_of(rank)]
         return np.concatenate(ids) if ids else np.zeros(0, dtype=np.int64)
 
-    def assemble(self, gathered):
-        """gathered: [G, max_rays, C] (numpy or torch) -> [H*W, C] image in global pixel order."""
+    def pixel_ids_on(self, rank: int, device):
+        """pixel_ids(rank) as an int64 tensor on `device`, cached: the un-permute of every frame reuses it."""
+        import torch
+        key = (rank, str(device))
+        if key not in self._ids:
+            self._ids[key] = torch.from_numpy(self.pixel_ids(rank)).to(device)
+        return self._ids[key]
+
+    def assemble(self, gathered, out=None):
+        """gathered: [G, max_rays, C] (numpy or torch), or a list of G [max_rays, C] tensors -> [H*W, C] image in global pixel order."""
         import torch
         is_np = isinstance(gathered, np.ndarray)
         g = torch.from_numpy(gathered) if is_np else gathered
-        out = torch.zeros((self.npix,) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+        first = g[0]
+        if out is None:
+            out = torch.zeros((self.npix,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
         for r in range(self.g):
-            ids = torch.from_numpy(self.pixel_ids(r)).to(g.device)
-            out[ids] = g[r, : ids.numel()]
+            ids = self.pixel_ids_on(r, first.device)
+            out[ids] = g[r][: ids.numel()]
         return out.numpy() if is_np else out
 
 
-def gather_to_root(local, plan: RowTilePlan, rank: int, group=None):
-    """One gather (RCCL over xGMI on GPUs, gloo on CPU) of every rank's padded tile buffer to rank 0.
+class Gatherer:
+    """The exchange step of a frame: ONE gather (RCCL over xGMI on GPUs, gloo on CPU) of every rank's padded tile buffer
+    to rank 0, then the un-permute into image order.  Send buffer, receive list, pixel-id tensors and the image are
+    allocated once and reused for every frame."""
 
-    local: torch tensor [n_rays(rank), C].  Returns the assembled [H*W, C] image on rank 0, None elsewhere.
-    """
-    import torch
-    import torch.distributed as dist
-    pad = plan.max_rays()
-    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    buf[: local.shape[0]] = local
-    if plan.g == 1 or not dist.is_initialized():
-        return plan.assemble(buf.unsqueeze(0))
-    if rank == 0:
-        parts = [torch.empty_like(buf) for _ in range(plan.g)]
-        dist.gather(buf, gather_list=parts, dst=0, group=group)
-        return plan.assemble(torch.stack(parts))
-    dist.gather(buf, gather_list=None, dst=0, group=group)
-    return None
+    def __init__(self, plan: RowTilePlan, rank: int, group=None):
+        self.plan, self.rank, self.group = plan, rank, group
+        self._buf = self._parts = self._image = None
+
+    def __call__(self, local):
+        """local: torch tensor [n_rays(rank), C].  Returns the assembled [H*W, C] image on rank 0, None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        plan = self.plan
+        shape = (plan.max_rays(),) + tuple(local.shape[1:])
+        if self._buf is None or self._buf.shape != shape or self._buf.dtype != local.dtype or self._buf.device != local.device:
+            self._buf = torch.zeros(shape, dtype=local.dtype, device=local.device)
+            self._parts = [torch.empty_like(self._buf) for _ in range(plan.g)] if self.rank == 0 else None
+            self._image = torch.zeros((plan.npix,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) if self.rank == 0 else None
+        self._buf[: local.shape[0]] = local
+        if plan.g == 1 or not dist.is_initialized():
+            return plan.assemble([self._buf], out=self._image)
+        if self.rank == 0:
+            dist.gather(self._buf, gather_list=self._parts, dst=0, group=self.group)
+            return plan.assemble(self._parts, out=self._image)
+        dist.gather(self._buf, gather_list=None, dst=0, group=self.group)
+        return None
+
+
+def gather_to_root(local, plan: RowTilePlan, rank: int, group=None):
+    """One-off form of Gatherer (allocates per call)."""
+    return Gatherer(plan, rank, group)(local)
 
 
 class ShardedRenderer:

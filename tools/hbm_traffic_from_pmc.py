@@ -22,11 +22,11 @@ entry = {
     "fetch_size_kb_raw": fetch[dom], "write_size_kb_raw": write.get(dom, 0.0), "kernel": dom.replace("void ", ""),
     "resolve_pass_hbm_bytes": int(sum(fetch[k] * 2 * 1024 + write.get(k, 0.0) * 1024 for k in res)) if res else 0,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
-              "(profiles/r01_final_bench_pmc_*.csv); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B; the reads "
+              "(profiles/r02_bench_pmc_*.csv); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B; the reads "
               "here are 8-B and 4-B per lane, for which the guide calls the factor uncalibrated, so this is an upper bound). The traffic is the "
               "path-history work buffer (8 B per scan written and read back) and the per-sample radiance scratch of the sample-chunked launch, "
-              "not triangle data: the 480 KB triangle streams stay in L2/LDS",
-    "round": 1,
+              "not triangle data: the 320 KB + 480 KB record streams stay in L2/LDS",
+    "round": 2,
 }
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
