@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPHIP_ABI_VERSION 1
+#define SPHIP_ABI_VERSION 2
 
 typedef struct sphip_ctx sphip_t;
 
@@ -84,12 +84,35 @@ typedef struct {
 	uint64_t n_pixels;
 	uint32_t kernel_variant;   /* variant that actually ran */
 	uint32_t n_launches;
+	/* multi-device contexts (sphip_create_multi); a single-device context reports 1, 0, 0, kernel_ms */
+	uint32_t n_devices;        /* devices the last render ran on */
+	uint32_t gather_kind;      /* SPHIP_GATHER_* used to bring the row tiles to the first device */
+	double   gather_ms;        /* first tile copy enqueued -> image assembled on the first device (hipEvent on its stream) */
+	double   kernel_ms_min;    /* kernel_ms is the slowest device's, this the fastest's */
 } sphip_stats;
+
+enum {
+	SPHIP_GATHER_NONE = 0,     /* one device */
+	SPHIP_GATHER_RCCL = 1,     /* ncclSend/ncclRecv group over xGMI, single-process communicator (ncclCommInitAll) */
+	SPHIP_GATHER_PEER = 2      /* hipMemcpyPeerAsync per device (also what runs when a device id is listed twice, or RCCL is absent) */
+};
 
 /* ---- lifetime.  Replaces X_renderer::get(w,h) construction (src/cpu_renderer.cpp:205-209) for the
  * device-owning part; device buffers are cached grow-only in the context like
  * src/cl_renderer.cpp:107-112 and released by sphip_destroy. */
 int  sphip_create(int device_id, sphip_t** out);
+/* All the GPUs of one node behind ONE context, so that a renderer object registered beside cpu_renderer
+ * (src/main.cpp:242-248, interface src/renderer.h:24-36) drives every device: the framebuffer is dealt to the devices as
+ * interleaved pixel-row tiles (round-robin, sphip_plan_*), every device holds the whole scene and renders its tiles on its
+ * own stream from its own host thread, the RGBA8 tiles are gathered to the first device (RCCL over xGMI; peer copies as the
+ * fallback), un-permuted there and read back once.  The image is bit-identical to a one-device render (pixel-keyed RNG).
+ *   device_ids == NULL: every visible device, or the comma-separated list in the environment variable SPATH_HIP_DEVICES.
+ *   A device may be listed more than once (several shards on one GPU: how a one-GPU box exercises this path).
+ *   SPATH_HIP_GATHER=rccl|peer overrides the choice of exchange.
+ * The host-pointer entry points (sphip_set_scene, sphip_render, sphip_render_camera, sphip_get_stats, sphip_description,
+ * sphip_destroy) accept such a context; the device-pointer entry points need a single-device context (SPHIP_E_STATE). */
+int  sphip_create_multi(const int* device_ids, int n_devices, sphip_t** out);
+int  sphip_device_count(const sphip_t* ctx);        /* devices behind ctx (1 for sphip_create) */
 void sphip_destroy(sphip_t* ctx);
 const char* sphip_last_error(const sphip_t* ctx);   /* ctx may be NULL: error of a failed sphip_create */
 const char* sphip_description(const sphip_t* ctx);  /* renderer::get_description  src/renderer.h:26 */
@@ -141,6 +164,13 @@ int sphip_render_camera(sphip_t* ctx, const sphip_camera* cam, size_t n_samples,
  * Used by the parity tests to compare scan kernels hit for hit; asynchronous like sphip_render_device. */
 int sphip_closest_hit_device(sphip_t* ctx, const void* d_rays, size_t n_rays, const void* d_src_idx /* n_rays i32 or NULL */,
                              int flags, void* d_out_idx /* n_rays i32 */, void* d_out_dist /* n_rays f32 */, void* stream);
+
+/* The row-tile plan, pure host arithmetic (no GPU needed): tiles of `tile_rows` image rows are dealt round-robin, tile t to
+ * device t mod n_devices.  sphip_plan_tile_rows: the largest tile height <= 8 that gives every device the same number of
+ * whole tiles (8 when none does).  sphip_plan_shard: device `rank`'s sphip_shard and ray count; returns SPHIP_E_INVALID on
+ * nonsense arguments. */
+int sphip_plan_tile_rows(size_t height, int n_devices);
+int sphip_plan_shard(size_t width, size_t height, int n_devices, size_t tile_rows, int rank, sphip_shard* shard_out, size_t* n_rays_out);
 
 /* Blocks until the last render on this context has finished, then reports its figures. */
 int sphip_get_stats(sphip_t* ctx, sphip_stats* out);

@@ -29,7 +29,9 @@ SYMBOLS = (
     "sphip_create", "sphip_destroy", "sphip_last_error", "sphip_description", "sphip_abi_version",
     "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
     "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats", "sphip_viewport_device", "sphip_render_camera",
+    "sphip_create_multi", "sphip_device_count", "sphip_plan_tile_rows", "sphip_plan_shard",
 )
+GATHER_NONE, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 
 
 class Shard(C.Structure):
@@ -51,7 +53,8 @@ class CameraArgs(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double),
                 ("scans_executed", C.c_uint64), ("n_tris", C.c_uint64), ("n_pixels", C.c_uint64),
-                ("kernel_variant", C.c_uint32), ("n_launches", C.c_uint32)]
+                ("kernel_variant", C.c_uint32), ("n_launches", C.c_uint32),
+                ("n_devices", C.c_uint32), ("gather_kind", C.c_uint32), ("gather_ms", C.c_double), ("kernel_ms_min", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -101,6 +104,14 @@ def load():
     L.sphip_render_camera.argtypes = [vp, C.POINTER(CameraArgs), sz, C.c_uint64, C.c_int, C.c_int, vp, vp]
     L.sphip_get_stats.restype = C.c_int
     L.sphip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sphip_create_multi.restype = C.c_int
+    L.sphip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.sphip_device_count.restype = C.c_int
+    L.sphip_device_count.argtypes = [vp]
+    L.sphip_plan_tile_rows.restype = C.c_int
+    L.sphip_plan_tile_rows.argtypes = [sz, C.c_int]
+    L.sphip_plan_shard.restype = C.c_int
+    L.sphip_plan_shard.argtypes = [sz, sz, C.c_int, sz, C.c_int, C.POINTER(Shard), C.POINTER(sz)]
     _lib = L
     return L
 
@@ -118,17 +129,53 @@ def kernel_variants():
     return out
 
 
-class Context:
-    """One sphip_t: a device, its cached buffers and its scene."""
+def plan_tile_rows(height: int, n_devices: int) -> int:
+    """The library's row-tile height for a frame of `height` rows on n_devices GPUs (pure host arithmetic)."""
+    return load().sphip_plan_tile_rows(height, n_devices)
 
-    def __init__(self, device: int = 0):
+
+def plan_shard(width: int, height: int, n_devices: int, tile_rows: int, rank: int):
+    """((pixel_base, tile_px, tile_stride_px), n_rays) of device `rank` in the library's round-robin row-tile plan."""
+    sh, n = Shard(), C.c_size_t(0)
+    rc = load().sphip_plan_shard(width, height, n_devices, tile_rows, rank, C.byref(sh), C.byref(n))
+    if rc != 0:
+        raise SpathHipError(f"sphip_plan_shard: bad arguments [{rc}]")
+    return (sh.pixel_base, sh.tile_px, sh.tile_stride_px), n.value
+
+
+class Context:
+    """One sphip_t: a device (or, from Context.multi, several), its cached buffers and its scene."""
+
+    def __init__(self, device: int = 0, _handle=None):
         self._L = load()
+        if _handle is not None:
+            self._h, self.device = _handle, None
+            return
         h = C.c_void_p()
         rc = self._L.sphip_create(device, C.byref(h))
         if rc != 0:
             raise SpathHipError(f"sphip_create({device}) failed [{rc}]: {self._L.sphip_last_error(None).decode()}")
         self._h = h
         self.device = device
+
+    @classmethod
+    def multi(cls, device_ids=None):
+        """sphip_create_multi: every listed device behind one context (None: all visible devices / SPATH_HIP_DEVICES).
+        Only the host-pointer calls (set_scene, render, render_camera, stats) work on it."""
+        L = load()
+        h = C.c_void_p()
+        if device_ids is None:
+            rc = L.sphip_create_multi(None, 0, C.byref(h))
+        else:
+            arr = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            rc = L.sphip_create_multi(arr, len(device_ids), C.byref(h))
+        if rc != 0:
+            raise SpathHipError(f"sphip_create_multi({device_ids}) failed [{rc}]: {L.sphip_last_error(None).decode()}")
+        return cls(_handle=h)
+
+    @property
+    def device_count(self) -> int:
+        return self._L.sphip_device_count(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -78,6 +78,10 @@ struct ViewArgs {
 	float focal, cos_y, sin_y, cos_x, sin_x;
 	float px, py, pz;
 	uint32_t res_x, res_y;
+	// which pixels: ray k of the output is global pixel pixel_base + (k / tile_px) * tile_stride_px + k % tile_px (sphip_shard);
+	// the whole image is {0, res_x*res_y, 0} with n_local = res_x*res_y
+	uint64_t pixel_base, tile_px, tile_stride_px;
+	uint32_t n_local;
 };
 
 SP_DEV f3 cam_rel_move(const ViewArgs& v, f3 in) {                               // view.h:83-85 = rY(rX(in))
@@ -86,16 +90,30 @@ SP_DEV f3 cam_rel_move(const ViewArgs& v, f3 in) {                              
 }
 
 __global__ void __launch_bounds__(256) k_viewport(const ViewArgs v, float* __restrict__ rays) {
-	const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-	if (idx >= v.res_x * v.res_y) return;
+	const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+	if (k >= v.n_local) return;
+	const uint64_t tile = (uint64_t)k / v.tile_px;
+	const uint64_t idx = v.pixel_base + tile * v.tile_stride_px + ((uint64_t)k - tile * v.tile_px);
 	const int i = (int)(idx % v.res_x), j = (int)(idx / v.res_x);                 // :112 index = i + j*res_x
 	const f3 cur = mk3(v.x_max - v.x_step * (float)i - v.h_x_step, v.y_max - v.y_step * (float)j - v.h_y_step, 0.0f);   // :111
 	const f3 t = add3(cur, mk3(0.0f, 0.0f, v.focal));                             // :114
 	const float l = __builtin_sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);           // geom.h:130-136 (IEEE sqrt)
 	const f3 dir = cam_rel_move(v, mk3(t.x / l, t.y / l, t.z / l));               // :138-141 then view.h:127
 	const f3 pos = add3(cam_rel_move(v, cur), mk3(v.px, v.py, v.pz));             // view.h:126,131
-	float* o = rays + (size_t)idx * 6;
+	float* o = rays + (size_t)k * 6;
 	o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = dir.x; o[4] = dir.y; o[5] = dir.z;
+}
+
+// ---- reassembly of a frame rendered as interleaved row tiles on G devices (one padded buffer of `pad` pixels per device,
+// gathered to one device): out[p] = the p-th pixel of the image.  C = dwords per pixel (1: RGBA8, 3: float accumulators)
+template <int C>
+__global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ out, uint32_t npix,
+                                                 uint32_t tile_px, uint32_t n_dev, uint32_t pad) {
+	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+	if (p >= npix) return;
+	const uint32_t tile = p / tile_px, r = tile % n_dev, k = (tile / n_dev) * tile_px + (p - tile * tile_px);
+#pragma unroll
+	for (int c = 0; c < C; ++c) out[(size_t)p * C + c] = gathered[((size_t)r * pad + k) * C + c];
 }
 
 SP_DEV uint64_t shard_pixel(const KArgs& a, uint32_t k) {

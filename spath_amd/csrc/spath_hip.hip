@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
+#include <dlfcn.h>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -46,6 +49,15 @@ struct sphip_ctx {
 	std::string err;
 	std::string desc;
 	hipStream_t last_stream = nullptr;
+	// ---- multi-device context (sphip_create_multi): one child context per listed device; the exchange buffers live on the
+	// first child's device.  A single-device context has no kids.
+	std::vector<sphip_ctx*> kids;
+	int gather_kind = SPHIP_GATHER_NONE;
+	void* rccl_lib = nullptr;
+	std::vector<void*> comms;                     // ncclComm_t per child
+	DevBuf gath, gath_acc, img, img_acc;           // [n_dev][pad] tiles as gathered, and the image in pixel order
+	std::vector<hipEvent_t> ev_tile;               // child r's tiles have arrived on the first device
+	hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
 };
 
 namespace {
@@ -392,6 +404,233 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	return SPHIP_OK;
 }
 
+
+// ---- view::camera::get_viewport on the device for the pixels of a shard (sp_kernels.h: k_viewport)
+int launch_viewport(sphip_ctx* c, const sphip_camera* cam, void* d_rays, hipStream_t st, const sphip_shard* shard = nullptr, size_t n_local = 0) {
+	if (!cam || !d_rays) return fail(c, SPHIP_E_INVALID, "null camera or ray pointer");
+	if (cam->res_x == 0 || cam->res_y == 0 || (uint64_t)cam->res_x * cam->res_y > 0xffffffffull)
+		return fail(c, SPHIP_E_INVALID, "bad viewport size %ux%u", cam->res_x, cam->res_y);
+	sp::ViewArgs v{};
+	// view.h:101-108: `real` (float) variables initialised from double expressions
+	const float x_size = (float)(1.0 * (double)cam->res_x / (double)cam->res_y), y_size = 1.0f;
+	v.x_max = (float)((double)x_size / 2.0);
+	v.x_step = x_size / (float)cam->res_x;
+	v.h_x_step = (float)((double)v.x_step / 2.0);
+	v.y_max = (float)((double)y_size / 2.0);
+	v.y_step = y_size / (float)cam->res_y;
+	v.h_y_step = (float)((double)v.y_step / 2.0);
+	v.focal = cam->focal; v.cos_y = cam->cos_y; v.sin_y = cam->sin_y; v.cos_x = cam->cos_x; v.sin_x = cam->sin_x;
+	v.px = cam->pos[0]; v.py = cam->pos[1]; v.pz = cam->pos[2];
+	v.res_x = cam->res_x; v.res_y = cam->res_y;
+	const uint32_t n = shard ? (uint32_t)n_local : cam->res_x * cam->res_y;
+	v.n_local = n;
+	if (shard) { v.pixel_base = shard->pixel_base; v.tile_px = shard->tile_px; v.tile_stride_px = shard->tile_stride_px; }
+	else { v.pixel_base = 0; v.tile_px = n; v.tile_stride_px = 0; }
+	if (n == 0) return SPHIP_OK;
+	hipLaunchKernelGGL(sp::k_viewport, dim3((n + 255) / 256), dim3(256), 0, st, v, (float*)d_rays);
+	HIP_TRY(c, hipGetLastError());
+	return SPHIP_OK;
+}
+
+
+// =====================================================================================================================
+// All GPUs of a node behind one context (include/spath_hip.h: sphip_create_multi).  The reference has no multi-device
+// code; what is sharded is the pixel loop of cpu_renderer.cpp:70-79,118-184 (pixels are independent), behind the same
+// renderer::render / render_flat calls (src/renderer.h:31-32).
+// =====================================================================================================================
+
+// ---- the row-tile plan
+int plan_tile_rows(size_t height, int n_dev) {
+	for (int tr = 8; tr >= 1; --tr)
+		if (height % (size_t)tr == 0 && (height / (size_t)tr) % (size_t)n_dev == 0) return tr;
+	return 8;
+}
+
+struct RowPlan {
+	size_t w, h, tile_rows, tile_px, n_tiles, npix;
+	int g;
+	RowPlan(size_t w_, size_t h_, int g_, size_t tr) : w(w_), h(h_), tile_rows(tr), tile_px(tr * w_), n_tiles((h_ + tr - 1) / tr), npix(w_ * h_), g(g_) {}
+	size_t n_rays(int rank) const {
+		size_t n = 0;
+		for (size_t t = (size_t)rank; t < n_tiles; t += (size_t)g) n += std::min(tile_px, npix - t * tile_px);
+		return n;
+	}
+	size_t max_rays() const { size_t m = 0; for (int r = 0; r < g; ++r) m = std::max(m, n_rays(r)); return m; }
+	sphip_shard shard(int rank) const { return sphip_shard{ (uint64_t)rank * tile_px, (uint64_t)tile_px, (uint64_t)g * tile_px }; }
+};
+
+// ---- RCCL, loaded on first use: the single-GPU path (and every process that never creates a multi-device context) does not
+// depend on librccl being present
+typedef int (*nccl_init_all_t)(void**, int, const int*);
+typedef int (*nccl_comm_destroy_t)(void*);
+typedef int (*nccl_group_t)(void);
+typedef int (*nccl_send_t)(const void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_recv_t)(void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_t)(int);
+struct Rccl {
+	nccl_init_all_t init_all = nullptr; nccl_comm_destroy_t destroy = nullptr; nccl_group_t group_start = nullptr, group_end = nullptr;
+	nccl_send_t send = nullptr; nccl_recv_t recv = nullptr; nccl_errstr_t errstr = nullptr;
+} g_rccl;
+constexpr int kNcclUint8 = 1;      // ncclDataType_t::ncclUint8 (rccl.h)
+
+void* load_rccl() {
+	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	for (const char* n : names) {
+		void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+		if (!h) continue;
+		g_rccl.init_all = (nccl_init_all_t)dlsym(h, "ncclCommInitAll");
+		g_rccl.destroy = (nccl_comm_destroy_t)dlsym(h, "ncclCommDestroy");
+		g_rccl.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
+		g_rccl.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+		g_rccl.send = (nccl_send_t)dlsym(h, "ncclSend");
+		g_rccl.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
+		g_rccl.errstr = (nccl_errstr_t)dlsym(h, "ncclGetErrorString");
+		if (g_rccl.init_all && g_rccl.destroy && g_rccl.group_start && g_rccl.group_end && g_rccl.send && g_rccl.recv) return h;
+		dlclose(h);
+	}
+	return nullptr;
+}
+
+int multi_set_scene(sphip_ctx* c, const float* tris, const float* mats, size_t n_tris) {
+	const int g = (int)c->kids.size();
+	std::vector<int> rcs((size_t)g, SPHIP_OK);
+	std::vector<std::thread> th;
+	for (int r = 0; r < g; ++r) th.emplace_back([&, r] { rcs[(size_t)r] = sphip_set_scene(c->kids[(size_t)r], tris, mats, n_tris); });   // every device holds the whole scene
+	for (auto& t : th) t.join();
+	for (int r = 0; r < g; ++r)
+		if (rcs[(size_t)r]) return fail(c, rcs[(size_t)r], "device %d: %s", c->kids[(size_t)r]->device, c->kids[(size_t)r]->err.c_str());
+	c->n_tris = n_tris;
+	c->have_scene = true;
+	return SPHIP_OK;
+}
+
+// rays != nullptr: the caller's viewport (host array, w*h rays); else cam: every device generates the rays of its own tiles
+int multi_render(sphip_ctx* c, const float* rays, const sphip_camera* cam, size_t w, size_t h, size_t n_samples, uint64_t seed, int mode, int flags,
+                 uint8_t* out_rgba, float* out_accum) {
+	if (!c->have_scene) return fail(c, SPHIP_E_STATE, "render called before a scene was set");
+	if (!out_rgba || w == 0 || h == 0 || w * h > 0xffffffffull) return fail(c, SPHIP_E_INVALID, "bad render arguments (w=%zu h=%zu)", w, h);
+	if (mode == SPHIP_MODE_PT && (n_samples == 0 || n_samples > 0x7fffffffull))
+		return fail(c, SPHIP_E_INVALID, "n_samples must be in [1, 2^31) (the reference divides by it, cpu_renderer.cpp:77)");
+	const int g = (int)c->kids.size();
+	const RowPlan plan(w, h, g, (size_t)plan_tile_rows(h, g));
+	const size_t pad = plan.max_rays(), npix = plan.npix;
+	sphip_ctx* root = c->kids[0];
+	HIP_TRY(c, hipSetDevice(root->device));
+	int rc;
+	if ((rc = ensure(c, c->gath, (size_t)g * pad * 4)) || (rc = ensure(c, c->img, npix * 4))) return rc;
+	if (out_accum && ((rc = ensure(c, c->gath_acc, (size_t)g * pad * 12)) || (rc = ensure(c, c->img_acc, npix * 12)))) return rc;
+	HIP_TRY(c, hipEventRecord(c->ev_g0, root->own_stream));
+	const bool peer = c->gather_kind != SPHIP_GATHER_RCCL;
+	std::vector<int> rcs((size_t)g, SPHIP_OK);
+	std::vector<std::thread> th;
+	for (int r = 0; r < g; ++r) th.emplace_back([&, r] {
+		sphip_ctx* k = c->kids[(size_t)r];
+		auto body = [&]() -> int {
+			const size_t n = plan.n_rays(r);
+			k->have_render = false;
+			if (n == 0) return SPHIP_OK;
+			HIP_TRY(k, hipSetDevice(k->device));
+			hipStream_t st = k->own_stream;
+			int rc2;
+			if ((rc2 = ensure(k, k->rays, n * 24)) || (rc2 = ensure(k, k->rgba, pad * 4))) return rc2;
+			if (out_accum && (rc2 = ensure(k, k->accum, pad * 12))) return rc2;
+			const sphip_shard sh = plan.shard(r);
+			if (rays) {           // this device's tiles of the caller's viewport, one copy per tile
+				size_t k0 = 0;
+				for (size_t t = (size_t)r; t < plan.n_tiles; t += (size_t)g) {
+					const size_t cnt = std::min(plan.tile_px, npix - t * plan.tile_px);
+					HIP_TRY(k, hipMemcpyAsync((char*)k->rays.p + k0 * 24, rays + t * plan.tile_px * 6, cnt * 24, hipMemcpyHostToDevice, st));
+					k0 += cnt;
+				}
+			} else if ((rc2 = launch_viewport(k, cam, k->rays.p, st, &sh, n))) return rc2;
+			if ((rc2 = launch_render(k, k->rays.p, n, &sh, w, n_samples, seed, mode, flags, k->rgba.p, out_accum ? k->accum.p : nullptr, st))) return rc2;
+			k->timed_upload = k->timed_download = false;
+			if (peer) {           // tiles -> slot r of the first device's gather buffer, in stream order behind the kernels
+				const bool same = k->device == root->device;      // a device listed twice, or the first device itself: a local copy
+				if (same) HIP_TRY(k, hipMemcpyAsync((char*)c->gath.p + (size_t)r * pad * 4, k->rgba.p, n * 4, hipMemcpyDeviceToDevice, st));
+				else HIP_TRY(k, hipMemcpyPeerAsync((char*)c->gath.p + (size_t)r * pad * 4, root->device, k->rgba.p, k->device, n * 4, st));
+				if (out_accum && same) HIP_TRY(k, hipMemcpyAsync((char*)c->gath_acc.p + (size_t)r * pad * 12, k->accum.p, n * 12, hipMemcpyDeviceToDevice, st));
+				else if (out_accum) HIP_TRY(k, hipMemcpyPeerAsync((char*)c->gath_acc.p + (size_t)r * pad * 12, root->device, k->accum.p, k->device, n * 12, st));
+				HIP_TRY(k, hipEventRecord(c->ev_tile[(size_t)r], st));
+			}
+			return SPHIP_OK;
+		};
+		rcs[(size_t)r] = body();
+	});
+	for (auto& t : th) t.join();
+	for (int r = 0; r < g; ++r)
+		if (rcs[(size_t)r]) return fail(c, rcs[(size_t)r], "device %d: %s", c->kids[(size_t)r]->device, c->kids[(size_t)r]->err.c_str());
+	HIP_TRY(c, hipSetDevice(root->device));
+	hipStream_t rs = root->own_stream;
+	if (peer) {
+		for (int r = 1; r < g; ++r) if (plan.n_rays(r)) HIP_TRY(c, hipStreamWaitEvent(rs, c->ev_tile[(size_t)r], 0));
+	} else {
+		// one grouped exchange: every other device sends its tiles, the first device receives them into its gather buffer;
+		// its own tiles are a local copy
+		if (plan.n_rays(0)) {
+			HIP_TRY(c, hipMemcpyAsync(c->gath.p, root->rgba.p, plan.n_rays(0) * 4, hipMemcpyDeviceToDevice, rs));
+			if (out_accum) HIP_TRY(c, hipMemcpyAsync(c->gath_acc.p, root->accum.p, plan.n_rays(0) * 12, hipMemcpyDeviceToDevice, rs));
+		}
+		int nrc = g_rccl.group_start();
+		for (int r = 1; r < g && !nrc; ++r) {
+			const size_t n = plan.n_rays(r);
+			if (!n) continue;
+			sphip_ctx* k = c->kids[(size_t)r];
+			if (!nrc) nrc = g_rccl.send(k->rgba.p, n * 4, kNcclUint8, 0, c->comms[(size_t)r], k->own_stream);
+			if (!nrc) nrc = g_rccl.recv((char*)c->gath.p + (size_t)r * pad * 4, n * 4, kNcclUint8, r, c->comms[0], rs);
+			if (out_accum && !nrc) nrc = g_rccl.send(k->accum.p, n * 12, kNcclUint8, 0, c->comms[(size_t)r], k->own_stream);
+			if (out_accum && !nrc) nrc = g_rccl.recv((char*)c->gath_acc.p + (size_t)r * pad * 12, n * 12, kNcclUint8, r, c->comms[0], rs);
+		}
+		const int erc = g_rccl.group_end();
+		if (nrc || erc) return fail(c, SPHIP_E_DEVICE, "RCCL gather failed: %s", g_rccl.errstr ? g_rccl.errstr(nrc ? nrc : erc) : "?");
+	}
+	const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+	hipLaunchKernelGGL(sp::k_assemble<1>, grid, block, 0, rs, (const uint32_t*)c->gath.p, (uint32_t*)c->img.p, (uint32_t)npix, (uint32_t)plan.tile_px, (uint32_t)g, (uint32_t)pad);
+	if (out_accum)
+		hipLaunchKernelGGL(sp::k_assemble<3>, grid, block, 0, rs, (const uint32_t*)c->gath_acc.p, (uint32_t*)c->img_acc.p, (uint32_t)npix, (uint32_t)plan.tile_px, (uint32_t)g, (uint32_t)pad);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipEventRecord(c->ev_g1, rs));
+	HIP_TRY(c, hipMemcpyAsync(out_rgba, c->img.p, npix * 4, hipMemcpyDeviceToHost, rs));
+	if (out_accum) HIP_TRY(c, hipMemcpyAsync(out_accum, c->img_acc.p, npix * 12, hipMemcpyDeviceToHost, rs));
+	HIP_TRY(c, hipStreamSynchronize(rs));            // blocking, like every reference backend (main.cpp:70-83)
+	for (int r = 1; r < g; ++r) {                    // the other devices' streams are idle now too (their last work fed the gather)
+		HIP_TRY(c, hipSetDevice(c->kids[(size_t)r]->device));
+		HIP_TRY(c, hipStreamSynchronize(c->kids[(size_t)r]->own_stream));
+	}
+	c->have_render = true;
+	c->stats.n_pixels = npix;
+	c->stats.n_tris = c->n_tris;
+	return SPHIP_OK;
+}
+
+int multi_get_stats(sphip_ctx* c, sphip_stats* out) {
+	if (!c->have_render) return fail(c, SPHIP_E_STATE, "no render has been issued yet");
+	sphip_stats s{};
+	s.kernel_ms_min = 1e300;
+	for (sphip_ctx* k : c->kids) {
+		if (!k->have_render) continue;
+		sphip_stats ks;
+		const int rc = sphip_get_stats(k, &ks);
+		if (rc) return fail(c, rc, "device %d: %s", k->device, k->err.c_str());
+		s.kernel_ms = std::max(s.kernel_ms, ks.kernel_ms);
+		s.kernel_ms_min = std::min(s.kernel_ms_min, ks.kernel_ms);
+		s.scans_executed += ks.scans_executed;
+		s.kernel_variant = ks.kernel_variant;
+		s.n_launches = ks.n_launches;
+		++s.n_devices;
+	}
+	HIP_TRY(c, hipSetDevice(c->kids[0]->device));
+	float ms = 0.0f;
+	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_g0, c->ev_g1));   // includes the first device's own kernels: report what is beyond them
+	s.gather_ms = std::max(0.0, (double)ms - s.kernel_ms);
+	s.gather_kind = (uint32_t)c->gather_kind;
+	s.n_tris = c->n_tris;
+	s.n_pixels = c->stats.n_pixels;
+	c->stats = s;
+	*out = s;
+	return SPHIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -401,6 +640,91 @@ int sphip_abi_version(void) { return SPHIP_ABI_VERSION; }
 const char* sphip_kernel_name(int variant) {
 	if (variant < 0 || variant > kVariantLast) return nullptr;
 	return kVariantNames[variant];
+}
+
+int sphip_plan_tile_rows(size_t height, int n_devices) {
+	if (height == 0 || n_devices < 1) return SPHIP_E_INVALID;
+	return plan_tile_rows(height, n_devices);
+}
+
+int sphip_plan_shard(size_t width, size_t height, int n_devices, size_t tile_rows, int rank, sphip_shard* shard_out, size_t* n_rays_out) {
+	if (width == 0 || height == 0 || n_devices < 1 || tile_rows == 0 || rank < 0 || rank >= n_devices) return SPHIP_E_INVALID;
+	const RowPlan plan(width, height, n_devices, tile_rows);
+	if (shard_out) *shard_out = plan.shard(rank);
+	if (n_rays_out) *n_rays_out = plan.n_rays(rank);
+	return SPHIP_OK;
+}
+
+int sphip_device_count(const sphip_t* c) { return c ? (c->kids.empty() ? 1 : (int)c->kids.size()) : 0; }
+
+int sphip_create_multi(const int* device_ids, int n_devices, sphip_t** out) {
+	if (!out) return fail(nullptr, SPHIP_E_INVALID, "out is NULL");
+	*out = nullptr;
+	std::vector<int> ids;
+	if (device_ids) {
+		if (n_devices < 1 || n_devices > 64) return fail(nullptr, SPHIP_E_INVALID, "n_devices %d out of range [1,64]", n_devices);
+		ids.assign(device_ids, device_ids + n_devices);
+	} else if (const char* env = getenv("SPATH_HIP_DEVICES")) {
+		for (const char* p = env; *p;) {
+			char* end = nullptr;
+			const long v = strtol(p, &end, 10);
+			if (end == p) return fail(nullptr, SPHIP_E_INVALID, "SPATH_HIP_DEVICES=\"%s\" is not a comma-separated list of device numbers", env);
+			ids.push_back((int)v);
+			p = (*end == ',') ? end + 1 : end;
+			if (*end && *end != ',') return fail(nullptr, SPHIP_E_INVALID, "SPATH_HIP_DEVICES=\"%s\" is not a comma-separated list of device numbers", env);
+		}
+		if (ids.empty() || ids.size() > 64) return fail(nullptr, SPHIP_E_INVALID, "SPATH_HIP_DEVICES lists %zu devices", ids.size());
+	} else {
+		int n = 0;
+		const hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0)
+			return fail(nullptr, SPHIP_E_DEVICE, "no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+		for (int i = 0; i < n; ++i) ids.push_back(i);
+	}
+	const char* want = getenv("SPATH_HIP_GATHER");
+	// one device: the plain context, no exchange step (unless the RCCL exchange is asked for explicitly: a communicator of one)
+	if (ids.size() == 1 && !(want && !strcmp(want, "rccl"))) return sphip_create(ids[0], out);
+	sphip_ctx* c = new (std::nothrow) sphip_ctx();
+	if (!c) return fail(nullptr, SPHIP_E_DEVICE, "out of host memory");
+	bool distinct = true;
+	for (size_t i = 0; i < ids.size(); ++i) for (size_t j = 0; j < i; ++j) distinct &= ids[i] != ids[j];
+	for (int id : ids) {
+		sphip_ctx* k = nullptr;
+		if (sphip_create(id, &k) != SPHIP_OK) { sphip_destroy(c); return SPHIP_E_DEVICE; }     // g_create_error already says why
+		c->kids.push_back(k);
+	}
+	sphip_ctx* root = c->kids[0];
+	c->device = root->device;
+	hipError_t e = hipSetDevice(root->device);
+	if (e == hipSuccess) e = hipEventCreate(&c->ev_g0);
+	if (e == hipSuccess) e = hipEventCreate(&c->ev_g1);
+	for (size_t r = 0; r < c->kids.size() && e == hipSuccess; ++r) {
+		hipEvent_t ev = nullptr;
+		if ((e = hipSetDevice(c->kids[r]->device)) == hipSuccess && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) == hipSuccess) c->ev_tile.push_back(ev);
+		// direct xGMI copies into the first device's gather buffer (not an error if already enabled or unsupported: the copy still works, staged)
+		if (e == hipSuccess && c->kids[r]->device != root->device) (void)hipDeviceEnablePeerAccess(root->device, 0);
+		(void)hipGetLastError();
+	}
+	if (e != hipSuccess) { fail(nullptr, SPHIP_E_DEVICE, "multi-device init failed: %s", hipGetErrorString(e)); sphip_destroy(c); return SPHIP_E_DEVICE; }
+	// exchange: RCCL when every listed device is a different GPU and librccl loads; peer copies otherwise
+	c->gather_kind = SPHIP_GATHER_PEER;
+	if (distinct && !(want && !strcmp(want, "peer"))) {
+		c->rccl_lib = load_rccl();
+		if (c->rccl_lib) {
+			c->comms.assign(ids.size(), nullptr);
+			const int nrc = g_rccl.init_all(c->comms.data(), (int)ids.size(), ids.data());
+			if (nrc == 0) c->gather_kind = SPHIP_GATHER_RCCL;
+			else { c->comms.clear(); if (want && !strcmp(want, "rccl")) { fail(nullptr, SPHIP_E_DEVICE, "ncclCommInitAll failed: %s", g_rccl.errstr ? g_rccl.errstr(nrc) : "?"); sphip_destroy(c); return SPHIP_E_DEVICE; } }
+		} else if (want && !strcmp(want, "rccl")) { fail(nullptr, SPHIP_E_DEVICE, "SPATH_HIP_GATHER=rccl but librccl could not be loaded: %s", dlerror()); sphip_destroy(c); return SPHIP_E_DEVICE; }
+	} else if (want && !strcmp(want, "rccl") && !distinct) {
+		fail(nullptr, SPHIP_E_INVALID, "SPATH_HIP_GATHER=rccl needs distinct devices (a communicator holds a GPU once)"); sphip_destroy(c); return SPHIP_E_INVALID;
+	}
+	char d[320];
+	snprintf(d, sizeof d, "HIP - Path Tracing (%zu devices, first: %s; pixel-row tiles, %s gather)", ids.size(),
+	         root->desc.c_str() + (root->desc.rfind("(") == std::string::npos ? 0 : root->desc.rfind("(") + 1), c->gather_kind == SPHIP_GATHER_RCCL ? "RCCL" : "peer-copy");
+	c->desc = d;
+	*out = c;
+	return SPHIP_OK;
 }
 
 int sphip_create(int device_id, sphip_t** out) {
@@ -438,6 +762,19 @@ int sphip_create(int device_id, sphip_t** out) {
 
 void sphip_destroy(sphip_t* c) {
 	if (!c) return;
+	if (!c->kids.empty()) {
+		for (void* comm : c->comms) if (comm) (void)g_rccl.destroy(comm);
+		(void)hipSetDevice(c->kids[0]->device);
+		(void)hipDeviceSynchronize();
+		DevBuf* mb[4] = { &c->gath, &c->gath_acc, &c->img, &c->img_acc };
+		for (auto b : mb) if (b->p) (void)hipFree(b->p);
+		if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
+		if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
+		for (size_t r = 0; r < c->ev_tile.size(); ++r) { (void)hipSetDevice(c->kids[r]->device); (void)hipEventDestroy(c->ev_tile[r]); }
+		for (sphip_ctx* k : c->kids) sphip_destroy(k);
+		delete c;
+		return;
+	}
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
 	DevBuf* bufs[17] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
@@ -456,6 +793,7 @@ const char* sphip_description(const sphip_t* c) { return c ? c->desc.c_str() : "
 int sphip_set_scene(sphip_t* c, const float* tris, const float* mats, size_t n_tris) {
 	if (!c) return SPHIP_E_INVALID;
 	if (!tris || !mats || n_tris == 0 || n_tris > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad scene arguments (n_tris=%zu)", n_tris);
+	if (!c->kids.empty()) return multi_set_scene(c, tris, mats, n_tris);
 	HIP_TRY(c, hipSetDevice(c->device));
 	int rc;
 	if ((rc = ensure(c, c->tris, n_tris * 48)) || (rc = ensure(c, c->mats, n_tris * 24))) return rc;
@@ -469,6 +807,7 @@ int sphip_set_scene(sphip_t* c, const float* tris, const float* mats, size_t n_t
 
 int sphip_set_scene_device(sphip_t* c, const void* d_tris, const void* d_mats, size_t n_tris, void* stream) {
 	if (!c) return SPHIP_E_INVALID;
+	if (!c->kids.empty()) return fail(c, SPHIP_E_STATE, "device-pointer entry points need a single-device context (sphip_create)");
 	if (!d_tris || !d_mats || n_tris == 0 || n_tris > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad scene arguments (n_tris=%zu)", n_tris);
 	HIP_TRY(c, hipSetDevice(c->device));
 	hipStream_t st = (hipStream_t)stream;
@@ -483,35 +822,15 @@ int sphip_set_scene_device(sphip_t* c, const void* d_tris, const void* d_mats, s
 int sphip_render_device(sphip_t* c, const void* d_rays, size_t n_rays, const sphip_shard* shard, size_t image_width,
                         size_t n_samples, uint64_t seed, int mode, int flags, void* d_out_rgba, void* d_out_accum, void* stream) {
 	if (!c) return SPHIP_E_INVALID;
+	if (!c->kids.empty()) return fail(c, SPHIP_E_STATE, "device-pointer entry points need a single-device context (sphip_create)");
 	HIP_TRY(c, hipSetDevice(c->device));
 	c->timed_upload = c->timed_download = false;
 	return launch_render(c, d_rays, n_rays, shard, image_width, n_samples, seed, mode, flags, d_out_rgba, d_out_accum, (hipStream_t)stream);
 }
 
-static int launch_viewport(sphip_ctx* c, const sphip_camera* cam, void* d_rays, hipStream_t st) {
-	if (!cam || !d_rays) return fail(c, SPHIP_E_INVALID, "null camera or ray pointer");
-	if (cam->res_x == 0 || cam->res_y == 0 || (uint64_t)cam->res_x * cam->res_y > 0xffffffffull)
-		return fail(c, SPHIP_E_INVALID, "bad viewport size %ux%u", cam->res_x, cam->res_y);
-	sp::ViewArgs v{};
-	// view.h:101-108: `real` (float) variables initialised from double expressions
-	const float x_size = (float)(1.0 * (double)cam->res_x / (double)cam->res_y), y_size = 1.0f;
-	v.x_max = (float)((double)x_size / 2.0);
-	v.x_step = x_size / (float)cam->res_x;
-	v.h_x_step = (float)((double)v.x_step / 2.0);
-	v.y_max = (float)((double)y_size / 2.0);
-	v.y_step = y_size / (float)cam->res_y;
-	v.h_y_step = (float)((double)v.y_step / 2.0);
-	v.focal = cam->focal; v.cos_y = cam->cos_y; v.sin_y = cam->sin_y; v.cos_x = cam->cos_x; v.sin_x = cam->sin_x;
-	v.px = cam->pos[0]; v.py = cam->pos[1]; v.pz = cam->pos[2];
-	v.res_x = cam->res_x; v.res_y = cam->res_y;
-	const uint32_t n = cam->res_x * cam->res_y;
-	hipLaunchKernelGGL(sp::k_viewport, dim3((n + 255) / 256), dim3(256), 0, st, v, (float*)d_rays);
-	HIP_TRY(c, hipGetLastError());
-	return SPHIP_OK;
-}
-
 int sphip_viewport_device(sphip_t* c, const sphip_camera* cam, void* d_rays_out, void* stream) {
 	if (!c) return SPHIP_E_INVALID;
+	if (!c->kids.empty()) return fail(c, SPHIP_E_STATE, "device-pointer entry points need a single-device context (sphip_create)");
 	HIP_TRY(c, hipSetDevice(c->device));
 	return launch_viewport(c, cam, d_rays_out, (hipStream_t)stream);
 }
@@ -520,6 +839,7 @@ int sphip_render_camera(sphip_t* c, const sphip_camera* cam, size_t n_samples, u
                         uint8_t* out_rgba, float* out_accum) {
 	if (!c) return SPHIP_E_INVALID;
 	if (!cam || !out_rgba) return fail(c, SPHIP_E_INVALID, "null camera or output pointer");
+	if (!c->kids.empty()) return multi_render(c, nullptr, cam, cam->res_x, cam->res_y, n_samples, seed, mode, flags, out_rgba, out_accum);
 	HIP_TRY(c, hipSetDevice(c->device));
 	const size_t n = (size_t)cam->res_x * cam->res_y;
 	hipStream_t st = c->own_stream;
@@ -541,6 +861,7 @@ int sphip_render_camera(sphip_t* c, const sphip_camera* cam, size_t n_samples, u
 int sphip_closest_hit_device(sphip_t* c, const void* d_rays, size_t n_rays, const void* d_src_idx, int flags,
                              void* d_out_idx, void* d_out_dist, void* stream) {
 	if (!c) return SPHIP_E_INVALID;
+	if (!c->kids.empty()) return fail(c, SPHIP_E_STATE, "device-pointer entry points need a single-device context (sphip_create)");
 	HIP_TRY(c, hipSetDevice(c->device));
 	c->timed_upload = c->timed_download = false;
 	return launch_render(c, d_rays, n_rays, nullptr, 0, 1, 0, kModeHits, flags, d_out_idx, d_out_dist, (hipStream_t)stream, (const int*)d_src_idx);
@@ -550,6 +871,7 @@ int sphip_render(sphip_t* c, const float* rays, size_t w, size_t h, size_t n_sam
                  uint8_t* out_rgba, float* out_accum) {
 	if (!c) return SPHIP_E_INVALID;
 	if (!rays || !out_rgba || w == 0 || h == 0) return fail(c, SPHIP_E_INVALID, "bad render arguments (w=%zu h=%zu)", w, h);
+	if (!c->kids.empty()) return multi_render(c, rays, nullptr, w, h, n_samples, seed, mode, flags, out_rgba, out_accum);
 	HIP_TRY(c, hipSetDevice(c->device));
 	const size_t n = w * h;
 	hipStream_t st = c->own_stream;
@@ -571,6 +893,7 @@ int sphip_render(sphip_t* c, const float* rays, size_t w, size_t h, size_t n_sam
 
 int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 	if (!c || !out) return SPHIP_E_INVALID;
+	if (!c->kids.empty()) return multi_get_stats(c, out);
 	if (!c->have_render) return fail(c, SPHIP_E_STATE, "no render has been issued yet");
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipEventSynchronize(c->ev_k1));
@@ -603,6 +926,7 @@ int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 		        x[1], x[2], x[3], x[4], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3]);
 	}
 #endif
+	c->stats.n_devices = 1; c->stats.gather_kind = SPHIP_GATHER_NONE; c->stats.gather_ms = 0.0; c->stats.kernel_ms_min = c->stats.kernel_ms;
 	*out = c->stats;
 	return SPHIP_OK;
 }

@@ -31,8 +31,10 @@ struct hip_r : public basic_renderer {
 	sphip_stats stats;
 	bool have_stats;
 
-	hip_r(const int x, const int y) : basic_renderer(x, y), ctx(0), seed(1), flags(0), scene_hash(0), scene_n(0), have_stats(false) {
-		if (sphip_create(0, &ctx) != SPHIP_OK)
+	// ids == 0: every visible GPU of the node (or the list in SPATH_HIP_DEVICES) behind this one renderer object: the frame is
+	// dealt to them as interleaved pixel-row tiles and reassembled on the first (include/spath_hip.h: sphip_create_multi)
+	hip_r(const int x, const int y, const int* ids, const int n_ids) : basic_renderer(x, y), ctx(0), seed(1), flags(0), scene_hash(0), scene_n(0), have_stats(false) {
+		if (sphip_create_multi(ids, n_ids, &ctx) != SPHIP_OK)
 			throw std::runtime_error(std::string("hip_renderer: ") + sphip_last_error(0));
 		desc = sphip_description(ctx);
 		std::memset(&stats, 0, sizeof stats);
@@ -110,7 +112,16 @@ struct hip_r : public basic_renderer {
 
 namespace hip_renderer {
 	scene::renderer* get(const int w, const int h) {
-		return new hip_r(w, h);
+		return new hip_r(w, h, 0, 0);
+	}
+
+	scene::renderer* get_on(const int w, const int h, const int* device_ids, const int n_devices) {
+		return new hip_r(w, h, device_ids, n_devices);
+	}
+
+	int device_count(scene::renderer* r) {
+		hip_r* p = dynamic_cast<hip_r*>(r);
+		return p ? sphip_device_count(p->ctx) : 0;
 	}
 
 	void set_seed(scene::renderer* r, unsigned long long seed) {

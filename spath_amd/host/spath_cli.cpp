@@ -5,7 +5,7 @@
 //
 //   spath_cli [--scene default|FILE.bin] [--w 640 --h 480] [--spp 128] [--mode pt|flat]
 //             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--out image.ppm|image.rgba] [--frames n]
-//             [--device-viewport]
+//             [--device-viewport] [--gpus n | --devices 0,1,...]
 #include "hip_renderer.h"
 
 #include <chrono>
@@ -66,6 +66,7 @@ int main(int argc, char** argv) {
 	try {
 		std::string scene_arg = "default", mode = "pt", out_path;
 		bool device_viewport = false;
+		std::vector<int> devices;                                    // empty: every visible GPU (hip_renderer::get)
 		int w = 640, h = 480, frames = 1, flags = 0;                 // window default of the reference (main.cpp:238-239)
 		size_t spp = 128;                                            // main.cpp:44
 		unsigned long long seed = 1;
@@ -83,6 +84,8 @@ int main(int argc, char** argv) {
 			else if (k == "--frames") { need(1); frames = std::atoi(argv[++i]); }
 			else if (k == "--out") { need(1); out_path = argv[++i]; }
 			else if (k == "--device-viewport") device_viewport = true;
+			else if (k == "--gpus") { need(1); const int n = std::atoi(argv[++i]); devices.clear(); for (int d = 0; d < n; ++d) devices.push_back(d); }
+			else if (k == "--devices") { need(1); devices.clear(); for (const char* p = argv[++i]; *p;) { char* e = 0; devices.push_back((int)std::strtol(p, &e, 10)); if (e == p) throw std::runtime_error("bad --devices list"); p = *e ? e + 1 : e; } }
 			else if (k == "--mov" || k == "--rot") { need(3); moves.push_back(std::make_pair(k[2], geom::vec3(std::atof(argv[i + 1]), std::atof(argv[i + 2]), std::atof(argv[i + 3])))); i += 3; }
 			else if (k == "--focal") { need(1); moves.push_back(std::make_pair('f', geom::vec3(std::atof(argv[++i]), 0, 0))); }
 			else throw std::runtime_error("unknown argument " + k);
@@ -92,10 +95,11 @@ int main(int argc, char** argv) {
 		if (scene_arg == "default") default_scene(tris, mats);
 		else if (!load_scene(scene_arg.c_str(), tris, mats)) throw std::runtime_error("cannot read scene file " + scene_arg);
 
-		std::unique_ptr<scene::renderer> r(hip_renderer::get(w, h));     // main.cpp:242-244
+		std::unique_ptr<scene::renderer> r(devices.empty() ? hip_renderer::get(w, h)      // main.cpp:242-244
+		                                                   : hip_renderer::get_on(w, h, devices.data(), (int)devices.size()));
 		hip_renderer::set_seed(r.get(), seed);
 		hip_renderer::set_flags(r.get(), flags);
-		std::printf("Current renderer: %s\n", r->get_description());     // main.cpp:30-32
+		std::printf("Current renderer: %s [%d device(s)]\n", r->get_description(), hip_renderer::device_count(r.get()));     // main.cpp:30-32
 		for (size_t k = 0; k < moves.size(); ++k) {
 			if (moves[k].first == 'm') r->set_delta_mov(moves[k].second);
 			else if (moves[k].first == 'r') r->set_delta_rot(moves[k].second);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     L = capi.load()
-    assert L.sphip_abi_version() == 1
+    assert L.sphip_abi_version() == 2
     assert L.sphip_kernel_name(0) == b"auto" and L.sphip_kernel_name(99) is None
     assert set(capi.kernel_variants()) >= {"auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_cyl2s", "rpl_cyl4s"}
 
