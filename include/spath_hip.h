@@ -172,6 +172,16 @@ int sphip_closest_hit_device(sphip_t* ctx, const void* d_rays, size_t n_rays, co
 int sphip_plan_tile_rows(size_t height, int n_devices);
 int sphip_plan_shard(size_t width, size_t height, int n_devices, size_t tile_rows, int rank, sphip_shard* shard_out, size_t* n_rays_out);
 
+/* TEST-ONLY: evaluates one device function of the path for n caller-supplied inputs (host pointers, blocking), so that the
+ * device arithmetic can be compared with the oracle directly rather than only through whole renders.
+ *   what 0  sincos_glibc   (std::sin/std::cos of geom.h:170-173)   in f32[n]                          out f32[2n] sin, cos
+ *        1  recip_ieee     (1.0/a of geom.h:206)                   in f32[n]                          out f32[n]
+ *        2  philox_uniforms (replaces frand.h:53-63)               in u32[5n] seed lo, hi, pixel, sample, depth   out f64[2n]
+ *        3  rand_unit_vec  (geom.h:164-177, the two draws given)   in f64[5n] n.xyz, r1, r2           out f32[3n]
+ *        4  ray_tri_strict (geom.h:197-222)                        in f32[15n] pos dir v0 v1 v2       out f32[n] distance or -1
+ *        5  vec3_rgba      (scene.h:32-39)                         in f32[3n]                         out u32[n] */
+int sphip_selftest_device(sphip_t* ctx, int what, const void* in, size_t n, void* out);
+
 /* Blocks until the last render on this context has finished, then reports its figures. */
 int sphip_get_stats(sphip_t* ctx, sphip_stats* out);
 

@@ -53,6 +53,7 @@ def lib():
         L.spo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.spo_counter_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.spo_device_math_batch.argtypes = [C.c_int, vp, C.c_size_t, vp, C.c_int]
         L.spo_ray_intersect.restype = C.c_float
         L.spo_ray_intersect.argtypes = [vp, vp, vp]
         L.spo_closest_hit.restype = C.c_int
@@ -110,6 +111,18 @@ def render_counter(rays, tris, mats, n_samples, seed, pix0=0, npix=None, workers
     lib().spo_render_counter(_p(rays), pix0, npix, _p(tris), _p(mats), tris.shape[0], n_samples,
                              C.c_uint64(seed), workers, _p(out), _p(acc), C.byref(scans))
     return out, acc, int(scans.value)
+
+
+MATH_OUT = {0: (np.float32, 2), 2: (np.float64, 2), 3: (np.float32, 3), 4: (np.float32, 1), 5: (np.uint32, 1)}
+
+
+def device_math(what, inp, n):
+    """Batch counterparts of the device functions sphip_selftest_device evaluates (same `what` codes, same layouts)."""
+    dt, k = MATH_OUT[what]
+    inp = np.ascontiguousarray(inp)
+    out = np.zeros(n * k, dtype=dt)
+    lib().spo_device_math_batch(what, _p(inp), n, _p(out), os.cpu_count() or 1)
+    return out
 
 
 def closest_hits(rays, tris, src_idx=None):

@@ -48,7 +48,8 @@ static const double SPO_PI = 3.14159265358979323846;
  * from the exact rounding by one ulp), so the published algorithm is restated here with its
  * published coefficients rather than replaced by a better one.  The GPU has no glibc, so the
  * oracle and the HIP kernel share this evaluation (separately rounded * and +, no FMA).
- * Pinned: tests/test_oracle_sincos.py checks it against libm on a dense sample and, through
+ * Pinned: tests/test_oracle_kat.py (test_sincos_matches_this_libm_on_dense_sample, test_sincos_matches_reference_libm_on_every_lcg_angle)
+ * checks it against libm on a dense sample and, through
  * the _ref KAT hash, on every angle the reference's 15-bit LCG can produce; an exhaustive
  * sweep of all 1,090,519,041 floats in [0, 8] found 0 mismatches against glibc 2.35
  * (oracle/sincos_exhaustive.c, run once, takes ~10 s).
@@ -451,4 +452,46 @@ void spo_camera_get_viewport(const spo_camera* c, spo_ray* rays) {       /* view
 	}
 	for (size_t k = 0; k < res_x * res_y; ++k)                           /* :130-131 */
 		rays[k].pos = v_add(rays[k].pos, c->pos);
+}
+
+
+/* ------------------------------------------------------------------ batch forms for the device self-test sweeps
+ * (tests/test_hip_device_math.py compares sphip_selftest_device against these on up to 1e9 inputs) */
+typedef struct { int what; size_t begin, end; const void* in; void* out; } batch_job;
+
+static void* batch_worker(void* arg) {
+	batch_job* j = (batch_job*)arg;
+	for (size_t i = j->begin; i < j->end; ++i) {
+		switch (j->what) {
+		case 0: { const float x = ((const float*)j->in)[i]; ((float*)j->out)[2 * i] = spo_sinf(x); ((float*)j->out)[2 * i + 1] = spo_cosf(x); break; }
+		case 2: { const uint32_t* q = (const uint32_t*)j->in + 5 * i;
+		          spo_counter_uniforms((uint64_t)q[0] | ((uint64_t)q[1] << 32), q[2], q[3], q[4], (double*)j->out + 2 * i, (double*)j->out + 2 * i + 1); break; }
+		case 3: { const double* q = (const double*)j->in + 5 * i; spo_vec3 n = { (float)q[0], (float)q[1], (float)q[2] };
+		          const spo_vec3 v = spo_rand_unit_vec_from(n, q[3], q[4]); float* o = (float*)j->out + 3 * i; o[0] = v.x; o[1] = v.y; o[2] = v.z; break; }
+		case 4: { const float* q = (const float*)j->in + 15 * i; spo_ray r = { { q[0], q[1], q[2] }, { q[3], q[4], q[5] } };
+		          spo_tri t = { { q[6], q[7], q[8] }, { q[9], q[10], q[11] }, { q[12], q[13], q[14] }, { 0, 0, 0 } }; spo_vec3 pt;
+		          ((float*)j->out)[i] = spo_ray_intersect(&r, &t, &pt); break; }
+		case 5: { const float* q = (const float*)j->in + 3 * i; spo_vec3 v = { q[0], q[1], q[2] }; const spo_rgba c = spo_vec3_rgba(v);
+		          ((uint32_t*)j->out)[i] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16) | ((uint32_t)c.a << 24); break; }
+		default: break;
+		}
+	}
+	return 0;
+}
+
+/* what: 0 sincos (in f32[n] -> out f32[2n]: sin, cos), 2 counter uniforms (u32[5n]: seed lo, seed hi, pixel, sample, depth -> f64[2n]),
+ * 3 rand_unit_vec (f64[5n]: n.xyz, r1, r2 -> f32[3n]), 4 ray_intersect (f32[15n]: pos dir v0 v1 v2 -> f32[n]), 5 vec3_RGBA (f32[3n] -> u32[n]).
+ * (1 = the IEEE reciprocal needs no oracle: numpy's float32 divide is it.) */
+void spo_device_math_batch(int what, const void* in, size_t n, void* out, int n_workers) {
+	if (n_workers < 1) n_workers = 1;
+	if ((size_t)n_workers > n && n > 0) n_workers = (int)n;
+	batch_job* jobs = (batch_job*)calloc((size_t)n_workers, sizeof(batch_job));
+	pthread_t* th = (pthread_t*)calloc((size_t)n_workers, sizeof(pthread_t));
+	for (int k = 0; k < n_workers; ++k) {
+		jobs[k].what = what; jobs[k].in = in; jobs[k].out = out;
+		jobs[k].begin = n * (size_t)k / (size_t)n_workers; jobs[k].end = n * (size_t)(k + 1) / (size_t)n_workers;
+		pthread_create(&th[k], 0, batch_worker, &jobs[k]);
+	}
+	for (int k = 0; k < n_workers; ++k) pthread_join(th[k], 0);
+	free(jobs); free(th);
 }

@@ -29,7 +29,7 @@ SYMBOLS = (
     "sphip_create", "sphip_destroy", "sphip_last_error", "sphip_description", "sphip_abi_version",
     "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
     "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats", "sphip_viewport_device", "sphip_render_camera",
-    "sphip_create_multi", "sphip_device_count", "sphip_plan_tile_rows", "sphip_plan_shard",
+    "sphip_create_multi", "sphip_device_count", "sphip_plan_tile_rows", "sphip_plan_shard", "sphip_selftest_device",
 )
 GATHER_NONE, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 
@@ -104,6 +104,8 @@ def load():
     L.sphip_render_camera.argtypes = [vp, C.POINTER(CameraArgs), sz, C.c_uint64, C.c_int, C.c_int, vp, vp]
     L.sphip_get_stats.restype = C.c_int
     L.sphip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sphip_selftest_device.restype = C.c_int
+    L.sphip_selftest_device.argtypes = [vp, C.c_int, vp, sz, vp]
     L.sphip_create_multi.restype = C.c_int
     L.sphip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.sphip_device_count.restype = C.c_int
@@ -248,6 +250,17 @@ class Context:
         self._check(self._L.sphip_render_camera(self._h, C.byref(ca), n_samples, seed, mode, flags, out.ctypes.data,
                                                 acc.ctypes.data if want_accum else None), "sphip_render_camera")
         return (out, acc) if want_accum else out
+
+    SELFTEST_OUT = {0: ("float32", 2), 1: ("float32", 1), 2: ("float64", 2), 3: ("float32", 3), 4: ("float32", 1), 5: ("uint32", 1)}
+
+    def selftest(self, what: int, inp, n: int):
+        """sphip_selftest_device (test-only): one device function of the path on n caller-supplied inputs."""
+        import numpy as np
+        dt, k = self.SELFTEST_OUT[what]
+        inp = np.ascontiguousarray(inp)
+        out = np.zeros(n * k, dtype=dt)
+        self._check(self._L.sphip_selftest_device(self._h, what, inp.ctypes.data, n, out.ctypes.data), "sphip_selftest_device")
+        return out
 
     def stats(self) -> dict:
         s = Stats()

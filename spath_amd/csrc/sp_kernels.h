@@ -116,6 +116,37 @@ __global__ void __launch_bounds__(256) k_assemble(const uint32_t* __restrict__ g
 	for (int c = 0; c < C; ++c) out[(size_t)p * C + c] = gathered[((size_t)r * pad + k) * C + c];
 }
 
+// ---- test-only: the device functions of the path on caller-supplied inputs (include/spath_hip.h: sphip_selftest_device)
+__global__ void __launch_bounds__(256) k_selftest(int what, const void* __restrict__ in, uint32_t n, void* __restrict__ out) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	if (what == 0) {
+		float sn, cs;
+		sincos_glibc(((const float*)in)[i], &sn, &cs);
+		((float*)out)[2 * i] = sn; ((float*)out)[2 * i + 1] = cs;
+	} else if (what == 1) {
+		((float*)out)[i] = recip_ieee(((const float*)in)[i]);
+	} else if (what == 2) {
+		const uint32_t* q = (const uint32_t*)in + 5 * (size_t)i;
+		double r1, r2;
+		philox_uniforms((uint64_t)q[0] | ((uint64_t)q[1] << 32), q[2], q[3], q[4], &r1, &r2);
+		((double*)out)[2 * i] = r1; ((double*)out)[2 * i + 1] = r2;
+	} else if (what == 3) {
+		const double* q = (const double*)in + 5 * (size_t)i;
+		const f3 v = rand_unit_vec(mk3((float)q[0], (float)q[1], (float)q[2]), q[3], q[4]);
+		float* o = (float*)out + 3 * (size_t)i;
+		o[0] = v.x; o[1] = v.y; o[2] = v.z;
+	} else if (what == 4) {
+		const float* q = (const float*)in + 15 * (size_t)i;
+		const f3 v0 = mk3(q[6], q[7], q[8]);
+		// e1, e2 as k_repack forms them: one float subtraction each (geom.h:200-201)
+		((float*)out)[i] = ray_tri_strict(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), v0, sub3(mk3(q[9], q[10], q[11]), v0), sub3(mk3(q[12], q[13], q[14]), v0));
+	} else if (what == 5) {
+		const float* q = (const float*)in + 3 * (size_t)i;
+		((uint32_t*)out)[i] = vec3_rgba(mk3(clamp01(q[0]), clamp01(q[1]), clamp01(q[2])));
+	}
+}
+
 SP_DEV uint64_t shard_pixel(const KArgs& a, uint32_t k) {
 	const uint64_t t = (uint64_t)k / a.tile_px;
 	return a.pixel_base + t * a.tile_stride_px + ((uint64_t)k - t * a.tile_px);

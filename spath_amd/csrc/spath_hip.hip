@@ -891,6 +891,28 @@ int sphip_render(sphip_t* c, const float* rays, size_t w, size_t h, size_t n_sam
 	return SPHIP_OK;
 }
 
+int sphip_selftest_device(sphip_t* c, int what, const void* in, size_t n, void* out) {
+	if (!c) return SPHIP_E_INVALID;
+	static const size_t in_b[6] = { 4, 4, 20, 40, 60, 12 }, out_b[6] = { 8, 4, 16, 12, 4, 4 };
+	if (what < 0 || what > 5 || !in || !out || n == 0 || n > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad selftest arguments (what=%d n=%zu)", what, n);
+	sphip_ctx* k = c->kids.empty() ? c : c->kids[0];
+	HIP_TRY(c, hipSetDevice(k->device));
+	void *d_in = nullptr, *d_out = nullptr;
+	HIP_TRY(c, hipMalloc(&d_in, n * in_b[what]));
+	hipError_t e = hipMalloc(&d_out, n * out_b[what]);
+	if (e == hipSuccess) e = hipMemcpy(d_in, in, n * in_b[what], hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(sp::k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k->own_stream, what, (const void*)d_in, (uint32_t)n, d_out);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(k->own_stream);
+	if (e == hipSuccess) e = hipMemcpy(out, d_out, n * out_b[what], hipMemcpyDeviceToHost);
+	(void)hipFree(d_in);
+	if (d_out) (void)hipFree(d_out);
+	if (e != hipSuccess) return fail(c, SPHIP_E_DEVICE, "selftest failed: %s", hipGetErrorString(e));
+	return SPHIP_OK;
+}
+
 int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 	if (!c || !out) return SPHIP_E_INVALID;
 	if (!c->kids.empty()) return multi_get_stats(c, out);

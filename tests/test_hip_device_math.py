@@ -1,0 +1,139 @@
+"""The device arithmetic of the path, function by function, against the oracle (include/spath_hip.h: sphip_selftest_device).
+Whole renders already agree bit for bit; these sweeps pin each function on its own, on far more inputs than a render
+reaches.  STATED TOLERANCE: 0 (bit patterns compared).
+
+  sincos_glibc     every float in [0, 2*pi] (1.09e9 values: the whole domain geom.h:168-173 can produce) and a sample up to 8
+  recip_ieee       every mantissa at 14 exponents incl. the denormal, 2^+-126 and inf/nan ends, both signs, against IEEE division
+  philox_uniforms  random and extreme counters/keys
+  rand_unit_vec    normals x draws of both generators (24-bit counter uniforms, all 32768 LCG values of frand.h:53-63)
+  ray_tri_strict   random, aimed-at-feature, grazing and degenerate (ray, triangle) pairs against geom::ray_intersect
+  vec3_rgba        every quantisation boundary
+"""
+import numpy as np
+import pytest
+
+from spath_amd import scene
+
+F = np.float32
+
+
+def test_oracle_batch_forms_equal_single_calls(O):
+    """CPU: spo_device_math_batch is the same code as the single-call functions the KATs pin."""
+    import ctypes as C
+    L = O.lib()
+    x = np.linspace(0, 6.3, 5000, dtype=F)
+    sc = O.device_math(0, x, x.size).reshape(-1, 2)
+    assert all(sc[i, 0].view(np.uint32) == np.float32(L.spo_sinf(C.c_float(float(x[i])))).view(np.uint32) for i in range(0, 5000, 7))
+    assert all(sc[i, 1].view(np.uint32) == np.float32(L.spo_cosf(C.c_float(float(x[i])))).view(np.uint32) for i in range(0, 5000, 7))
+    q = np.array([[1, 0, 5, 6, 2], [0xDEADBEEF, 0x12345, 0xFFFFFFFF, 0, 4]], dtype=np.uint32)
+    u = O.device_math(2, q, 2).reshape(-1, 2)
+    r1, r2 = C.c_double(), C.c_double()
+    L.spo_counter_uniforms(C.c_uint64(0x12345DEADBEEF), 0xFFFFFFFF, 0, 4, C.byref(r1), C.byref(r2))
+    assert u[1, 0] == r1.value and u[1, 1] == r2.value and 0 <= u.min() and u.max() < 1
+    rgba = O.device_math(5, np.array([[0.5, 2.0, -1.0]], dtype=F), 1)
+    assert rgba[0] == (128 | (255 << 8))
+
+
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_sincos_every_float_in_zero_to_two_pi(hip, O):
+    hi = int(np.float32(2.0 * np.pi).view(np.uint32)) + 2          # geom.h:168: float(r * PI * 2.0), r <= 1
+    step = 1 << 24
+    for lo in range(0, hi, step):
+        x = np.arange(lo, min(lo + step, hi), dtype=np.uint32).view(F)
+        got, want = hip.selftest(0, x, x.size), O.device_math(0, x, x.size)
+        bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+        assert bad.size == 0, (lo, bad[:5], x[bad[:5] // 2])
+    x = np.random.default_rng(1).uniform(6.28, 8.0, 1 << 20).astype(F)      # the restated algorithm's fast-reduction range continues to 120
+    assert np.array_equal(hip.selftest(0, x, x.size).view(np.uint32), O.device_math(0, x, x.size).view(np.uint32))
+
+
+@gpu
+def test_reciprocal_is_the_ieee_divide(hip):
+    man = np.arange(1 << 23, dtype=np.uint32)
+    with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+        for e in [0, 1, 2, 3, 64, 100, 126, 127, 128, 150, 200, 251, 252, 253, 254]:          # biased exponents; 0 = denormals
+            for sign in (0, 1):
+                x = (man | np.uint32(e << 23) | np.uint32(sign << 31)).view(F)
+                got, want = hip.selftest(1, x, x.size), (F(1.0) / x).astype(F)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (e, sign)
+        sp = np.array([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 3.4028235e38, 1.1754944e-38, 1e-14, -1e-14], dtype=F)
+        assert np.array_equal(hip.selftest(1, sp, sp.size).view(np.uint32), (F(1.0) / sp).astype(F).view(np.uint32))
+        nan = np.array([np.nan], dtype=F)
+        assert np.isnan(hip.selftest(1, nan, 1)[0])
+
+
+@gpu
+def test_philox_uniforms(hip, O):
+    rng = np.random.default_rng(2)
+    q = rng.integers(0, 1 << 32, (1 << 21, 5), dtype=np.uint64).astype(np.uint32)
+    q[:64] = np.array([[0, 0, 0, 0, 0], [0xFFFFFFFF] * 5, [1, 0, 0xFFFFFFFF, 0x7FFFFFFE, 4], [0, 1, 2073599, 255, 3]] * 16, dtype=np.uint32)
+    got, want = hip.selftest(2, q, q.shape[0]), O.device_math(2, q, q.shape[0])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and 0.0 <= got.min() and got.max() < 1.0
+
+
+@gpu
+def test_rand_unit_vec(hip, O):
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+    q = np.zeros((n, 5), dtype=np.float64)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[: n // 8] = np.eye(3)[rng.integers(0, 3, n // 8)] * rng.choice([-1.0, 1.0], (n // 8, 1))       # axis-aligned walls
+    q[:, :3] = nrm.astype(F)
+    q[:, 3:] = rng.integers(0, 1 << 24, (n, 2)) / 16777216.0                                            # counter uniforms: k / 2^24
+    k = np.arange(32768)
+    q[:32768, 3] = k / 32767.0; q[:32768, 4] = k[::-1] / 32767.0                                       # every value frand::seed_dist returns
+    q[32768:32776, 3:] = [[0, 0], [0, 1], [1, 0], [1, 1], [0.25, 0.5], [0.5, 0.25], [0.75, 16777215 / 16777216], [16777215 / 16777216, 0]]
+    got, want = hip.selftest(3, q, n), O.device_math(3, q, n)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _pairs(rng, t, n):
+    v = t[:, :9].reshape(-1, 3, 3).astype(np.float64)
+    tri = v[rng.integers(0, v.shape[0], n)]
+    w = rng.dirichlet([0.25, 0.25, 0.25], n)
+    w[: n // 4] = np.eye(3)[rng.integers(0, 3, n // 4)]                   # exactly at vertices
+    w[n // 4: n // 2, 2] = 0; w[n // 4: n // 2, :2] = rng.dirichlet([1, 1], n // 4)      # exactly on an edge
+    target = (tri * w[:, :, None]).sum(axis=1)
+    org = rng.uniform(-3.5, 3.5, (n, 3)) * [1, 0.4, 1] + [0, 0.5, 0]
+    d = target - org
+    d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True)    # the other half stays unnormalised
+    miss = rng.random(n) < 0.2
+    d[miss] = rng.normal(size=(int(miss.sum()), 3))
+    e = tri[:, 1] - tri[:, 0]
+    gr = rng.random(n) < 0.05                                              # grazing: origin in the triangle's plane, direction along an edge
+    org[gr] = (tri[gr, 2] - 2.0 * e[gr]); d[gr] = e[gr]
+    return np.concatenate([org, d, tri.reshape(n, 9)], axis=1).astype(F)
+
+
+@gpu
+def test_ray_tri_strict_is_geom_ray_intersect(hip, O):
+    rng = np.random.default_rng(4)
+    for t in (scene.closed_room(5000)[0], scene.default_scene()[0], scene.closed_room(600, clutter_scale=10.0)[0]):
+        q = _pairs(rng, t, 1 << 20)
+        q[:1000, 9:12] = q[:1000, 6:9]                                    # degenerate: v1 == v0
+        q[1000:2000, 12:15] = q[1000:2000, 9:12]                          # v2 == v1
+        q[2000:2100, 3:6] = 0.0                                           # zero direction
+        got, want = hip.selftest(4, q, q.shape[0]), O.device_math(4, q, q.shape[0])
+        assert (want > 0).mean() > 0.2
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # magnitudes across the float range (a ~ 1e-14 .. 1e14: both EPSILON tests of geom.h:204,217)
+    q = _pairs(rng, scene.closed_room(2000)[0], 1 << 18)
+    for s in (1e-9, 1e-5, 1e5, 1e9, 1e15):
+        z = q.copy(); z[:, :3] *= F(s); z[:, 6:] *= F(s)
+        assert np.array_equal(hip.selftest(4, z, z.shape[0]).view(np.uint32), O.device_math(4, z, z.shape[0]).view(np.uint32)), s
+
+
+@gpu
+def test_vec3_rgba_every_quantisation_boundary(hip, O):
+    k = np.arange(0, 256, dtype=np.float64)
+    edges = ((k + 0.5) / 255.0).astype(F)                                 # where (x*255 + 0.5) crosses an integer
+    near = np.concatenate([np.nextafter(edges, F(-1)), edges, np.nextafter(edges, F(2)), (k / 255.0).astype(F),
+                           np.array([-1.0, -0.0, 0.0, 1.0, 1.0000001, 2.0, 1e30, -1e30, 1e-30], dtype=F)])
+    rng = np.random.default_rng(5)
+    v = np.stack([near, rng.permutation(near), rng.uniform(-0.5, 1.5, near.size).astype(F)], axis=1)
+    assert np.array_equal(hip.selftest(5, v, v.shape[0]), O.device_math(5, v, v.shape[0]))
+    big = rng.uniform(-0.1, 1.1, (1 << 20, 3)).astype(F)
+    assert np.array_equal(hip.selftest(5, big, big.shape[0]), O.device_math(5, big, big.shape[0]))

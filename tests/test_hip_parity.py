@@ -280,8 +280,11 @@ def _block_means(img, w, h, b=8):
 
 def test_leg_c_statistical_agreement_with_reference_stream(hip, O, scenes):
     """HIP (counter RNG) vs the reference's own LCG stream (cpu_renderer semantics with T = 8, bit-pinned to
-    the reference by leg A), default scene 320x240 at 1024 spp.  Tolerances from reference-vs-reference noise
-    (image mean 0.035 %, block-mean Linf 3.25/255, block-mean mean|d| 0.22/255)."""
+    the reference by leg A), default scene 320x240 at 1024 spp.  Bounds of SURVEY.md 8(c): image mean within 0.2 %,
+    8x8 block means within 4/255.  Calibration (profiles/r02_leg_c_default_scene_calibration.log, tools/legc_default_calibration.py):
+    15 pairs of REFERENCE streams differ by 3.23 .. 5.73 (median 4.16) in block-mean Linf, 0.21 .. 0.22 in block-mean mean |d|,
+    up to 0.11 % in image mean; 12 HIP-vs-reference pairs by 3.45 .. 5.00 (median 4.14), 0.21 .. 0.23, up to 0.05 % -- the same
+    distribution.  This deterministic pair (seed 1 vs T = 8) measures 0.007 %, 3.77, 0.212."""
     t, m = scenes["default"]
     w, h, spp = 320, 240, 1024
     rays = view.Camera(w, h).get_viewport()
@@ -291,7 +294,7 @@ def test_leg_c_statistical_agreement_with_reference_stream(hip, O, scenes):
     mg, mr = got[:, :3].astype(np.float64).mean(), ref[:, :3].astype(np.float64).mean()
     assert abs(mg - mr) / mr <= 0.002, (mg, mr)                       # image-mean relative difference <= 0.2 %
     d = np.abs(_block_means(got, w, h) - _block_means(ref, w, h))
-    assert d.max() <= 6.0 and d.mean() <= 0.5, (d.max(), d.mean())    # of 255
+    assert d.max() <= 4.0 and d.mean() <= 0.25, (d.max(), d.mean())   # of 255
     # and the two images agree exactly where no randomness enters: pixels whose primary ray misses everything
     sky = (hip.render(rays, w, h, 1, mode=capi.MODE_FLAT).sum(axis=1) == 0)
     assert sky.sum() > 1000 and not got[sky].any() and not ref[sky].any()
@@ -381,6 +384,6 @@ def test_leg_c_closed_room_statistical_agreement(hip, O):
     hip.set_scene(t, m)
     got = hip.render(rays, w, h, spp, seed=1)
     mg, mr = got[:, :3].astype(np.float64).mean(), ref[:, :3].astype(np.float64).mean()
-    assert abs(mg - mr) / mr <= 0.004, (mg, mr)
+    assert abs(mg - mr) / mr <= 0.002, (mg, mr)
     d = np.abs(_block_means(got, w, h) - _block_means(ref, w, h))
-    assert d.max() <= 5.0 and d.mean() <= 0.9, (d.max(), d.mean())
+    assert d.max() <= 3.0 and d.mean() <= 0.6, (d.max(), d.mean())
