@@ -197,6 +197,9 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 	static_assert(R == 1 || R == 2 || R == 4, "bits per group must divide 32");
 	constexpr uint32_t kGPW = 32u / R;                 // groups of 4 triangles per 32-bit word
 	constexpr int kNW = (int)(64u / kGPW);             // words per tile
+	// the tile's bit words, [word][thread]: written once per word by the hot loop, read back by stage 2 when a lane moves on to
+	// its next non-empty word (in registers they would have to be picked and cleared through select cascades)
+	__shared__ uint32_t wq[kNW * 256];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t wbase = tid & ~63u;
 
@@ -241,7 +244,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kTile;
 		const uint32_t ngroups = ((left < (uint32_t)kTile ? left : (uint32_t)kTile) + 3u) / 4u;
 		// ---- stage 1: one bit per (group, slot); the first group ends up in the most significant bits
-		uint32_t word[kNW];
+		uint32_t nz = 0;                                  // bit wi: this lane's word wi has a bit set
 		uint32_t g = 0;
 #pragma unroll
 		for (int wi = 0; wi < kNW; ++wi) {
@@ -262,31 +265,34 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 				}
 			}
 			const uint32_t done = (g - g0) * R;                       // bits appended; left-align (wave-uniform shift)
-			word[wi] = done == 0u ? 0u : (wv << (32u - done));
+			const uint32_t wd = done == 0u ? 0u : (wv << (32u - done));
+			wq[wi * 256 + tid] = wd;
+			nz |= (wd != 0u ? 1u : 0u) << wi;
 		}
 		// the next tile streams in while the survivors are resolved
 		if (gt + 1u < total_tiles) cyl_tile_dma(cs.rec + (size_t)(gt + 1u) * kCylTileQ, sm + ((gt + 1u) & 1u) * kCylTileQ, tid, wbase);
 #ifdef SP_FILTER_STATS
 		uint32_t st_bits = 0, st_rounds = 0, st_exact = 0;      // experiment build only -> a.scans[1..4]
 #pragma unroll
-		for (int wi = 0; wi < kNW; ++wi) st_bits += (uint32_t)__builtin_popcount(word[wi]);
+		for (int wi = 0; wi < kNW; ++wi) st_bits += (uint32_t)__builtin_popcount(wq[wi * 256 + tid]);
 #endif
 		// ---- stage 2: every lane walks its set bits; one exact test per lane and round
 		uint32_t sub = 0;                                 // candidates of the current group already done (bit u)
+		uint32_t wid = nz ? (uint32_t)__builtin_ctz(nz) : 0u;      // current word of this lane and what is left of it
+		uint32_t curw = nz ? wq[wid * 256 + tid] : 0u;
 		for (;;) {
-			uint32_t any_w = 0;
-#pragma unroll
-			for (int wi = 0; wi < kNW; ++wi) any_w |= word[wi];
-			if (!__any(any_w != 0u)) break;
+			if (!__any(nz != 0u)) break;
 #ifdef SP_FILTER_STATS
 			++st_rounds;
 #endif
-			if (any_w != 0u) {
-				// first non-empty word, its first set bit
-				uint32_t wsel = word[kNW - 1], wid = kNW - 1;
-#pragma unroll
-				for (int wi = kNW - 2; wi >= 0; --wi) { const bool nz = word[wi] != 0u; wsel = nz ? word[wi] : wsel; wid = nz ? (uint32_t)wi : wid; }
-				const uint32_t e = (uint32_t)__builtin_clz(wsel);             // entry within the word
+			if (nz != 0u) {
+				// the lane's following non-empty word, requested now and used at the end of the round if the current one runs out
+				// (branch-free on purpose: a conditional reload makes the compiler nest the loop, and lanes then wait for
+				// each other at word boundaries)
+				const uint32_t nz2 = nz & (nz - 1u);
+				const uint32_t wid2 = (uint32_t)__builtin_ctz(nz2 | 0x80000000u) & (uint32_t)(kNW - 1);
+				const uint32_t nextw = wq[wid2 * 256 + tid];
+				const uint32_t e = (uint32_t)__builtin_clz(curw);             // first set bit: entry within the word
 				const uint32_t grp = wid * kGPW + e / R;
 				const int slot = (int)(e % R);
 				float Pa = f.Pa[0], Pb = f.Pb[0], Pc = f.Pc[0], ndx = f.ndx[0], ndy = f.ndy[0], ndz = f.ndz[0], D = f.D[0], Dq = f.Dq[0];
@@ -318,9 +324,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 				const uint32_t lowest = cand & (0u - cand);
 				const bool last = (cand == lowest);                             // no further survivor in this group
 				sub = last ? 0u : (sub | lowest);
-				const uint32_t clear = last ? ~(0x80000000u >> e) : 0xffffffffu;
-#pragma unroll
-				for (int wi = 0; wi < kNW; ++wi) word[wi] = (wid == (uint32_t)wi) ? (word[wi] & clear) : word[wi];
+				curw = last ? (curw & ~(0x80000000u >> e)) : curw;
 				if (cand != 0u) {
 #ifdef SP_FILTER_STATS
 					++st_exact;
@@ -334,6 +338,10 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 #pragma unroll
 					for (int r = 0; r < R; ++r) { const bool pick = (slot == r); bd[r] = pick ? best : bd[r]; bi[r] = pick ? besti : bi[r]; }
 				}
+				const bool adv = (curw == 0u);                                    // this word is done: on to the lane's next non-empty one
+				nz = adv ? nz2 : nz;
+				wid = adv ? wid2 : wid;
+				curw = adv ? nextw : curw;
 			}
 		}
 #ifdef SP_FILTER_STATS
