@@ -36,7 +36,16 @@
 
 namespace sp {
 
-constexpr uint32_t kCylTileQ = 2u * kTile;        // float4 per 256-triangle tile (8 KB)
+#ifndef SP_CYL_TILE
+#define SP_CYL_TILE 384
+#endif
+// Triangles per LDS tile.  Stage 2 runs once per tile and lasts as long as the lane with the most set bits needs; the maximum
+// over 64 lanes of a Poisson count grows more slowly than its mean, so larger tiles mean fewer stage-2 rounds per triangle
+// (measured, 4 rays per lane: 12.85 rounds per 256 triangles with 256-triangle tiles).  384 x 32 B, double-buffered, plus
+// the bit words (12 KB at 4 rays per lane) is what four workgroups per CU can afford (36 KB each).
+constexpr uint32_t kCylTile = SP_CYL_TILE;
+static_assert(kCylTile % 128 == 0, "whole waves per LDS-DMA pass, whole words of group bits");
+constexpr uint32_t kCylTileQ = 2u * kCylTile;     // float4 per tile
 
 struct CylStream {
 	const float4* rec;       // class-major stream; every class starts on a tile boundary
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(256) k_cyl_offsets(uint32_t* __restrict__ bloc
 	}
 	if (tid == 0) {
 		uint32_t tile = 0;
-		for (int k = 0; k < 3; ++k) { hdr[k] = total[k]; hdr[3 + k] = tile; tile += (total[k] + kTile - 1u) / kTile; }
+		for (int k = 0; k < 3; ++k) { hdr[k] = total[k]; hdr[3 + k] = tile; tile += (total[k] + kCylTile - 1u) / kCylTile; }
 		hdr[6] = tile;
 	}
 }
@@ -145,7 +154,7 @@ __global__ void __launch_bounds__(256) k_cyl_scatter(const float* __restrict__ t
 	__syncthreads();
 	if (cls >= 0) {
 		for (uint32_t v = 0; v < wv; ++v) rank += wave_cnt[v][cls];
-		const size_t pos = (size_t)hdr[3 + cls] * kTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
+		const size_t pos = (size_t)hdr[3 + cls] * kCylTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
 		rec[pos * 2 + 0] = q0;
 		rec[pos * 2 + 1] = q1;
 	}
@@ -156,20 +165,20 @@ __global__ void __launch_bounds__(256) k_cyl_scatter(const float* __restrict__ t
 // (k_repack pads the exact stream), i.e. a = 0, rejected at geom.h:204
 __global__ void __launch_bounds__(256) k_cyl_pad(const uint32_t* __restrict__ hdr, uint32_t n_tris, float4* __restrict__ rec) {
 	const uint32_t k = blockIdx.x, tid = threadIdx.x;
-	const uint32_t n = hdr[k], first = hdr[3 + k] * kTile;
-	const uint32_t pos = n + tid;
-	if (pos < (n + kTile - 1u) / kTile * kTile) {
+	const uint32_t n = hdr[k], first = hdr[3 + k] * kCylTile;
+	for (uint32_t pos = n + tid; pos < (n + kCylTile - 1u) / kCylTile * kCylTile; pos += 256u) {
 		rec[((size_t)first + pos) * 2 + 0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		rec[((size_t)first + pos) * 2 + 1] = make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f);
 	}
 }
 
-// one 8 KB tile global -> LDS by LDS-DMA: 2 x 16 B per thread
+// one tile global -> LDS by LDS-DMA: 16 B per lane, each wave instruction landing 1 KB contiguously
 SP_DEV void cyl_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, uint32_t wbase) {
 	typedef __attribute__((address_space(1))) const void* gptr_t;
 	typedef __attribute__((address_space(3))) void* lptr_t;
+	static_assert(kCylTileQ % 256 == 0, "whole workgroup passes");
 #pragma unroll
-	for (int p = 0; p < 2; ++p)
+	for (int p = 0; p < (int)(kCylTileQ / 256u); ++p)
 		__builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + tid), (lptr_t)(dst + p * 256 + wbase), 16, 0, 0);
 }
 
@@ -196,7 +205,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 	__shared__ float4 sm[2 * kCylTileQ];
 	static_assert(R == 1 || R == 2 || R == 4, "bits per group must divide 32");
 	constexpr uint32_t kGPW = 32u / R;                 // groups of 4 triangles per 32-bit word
-	constexpr int kNW = (int)(64u / kGPW);             // words per tile
+	constexpr int kNW = (int)((kCylTile / 4u) / kGPW);   // words per tile
 	// the tile's bit words, [word][thread]: written once per word by the hot loop, read back by stage 2 when a lane moves on to
 	// its next non-empty word (in registers they would have to be picked and cleared through select cascades)
 	__shared__ uint32_t wq[kNW * 256];
@@ -241,8 +250,8 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 			++cls;
 		}
 		const float4* cur = sm + (gt & 1u) * kCylTileQ;
-		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kTile;
-		const uint32_t ngroups = ((left < (uint32_t)kTile ? left : (uint32_t)kTile) + 3u) / 4u;
+		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kCylTile;
+		const uint32_t ngroups = ((left < kCylTile ? left : kCylTile) + 3u) / 4u;
 		// ---- stage 1: one bit per (group, slot); the first group ends up in the most significant bits
 		uint32_t nz = 0;                                  // bit wi: this lane's word wi has a bit set
 		uint32_t g = 0;
@@ -290,7 +299,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 				// (branch-free on purpose: a conditional reload makes the compiler nest the loop, and lanes then wait for
 				// each other at word boundaries)
 				const uint32_t nz2 = nz & (nz - 1u);
-				const uint32_t wid2 = (uint32_t)__builtin_ctz(nz2 | 0x80000000u) & (uint32_t)(kNW - 1);
+				const uint32_t wid2 = nz2 ? (uint32_t)__builtin_ctz(nz2) : 0u;
 				const uint32_t nextw = wq[wid2 * 256 + tid];
 				const uint32_t e = (uint32_t)__builtin_clz(curw);             // first set bit: entry within the word
 				const uint32_t grp = wid * kGPW + e / R;

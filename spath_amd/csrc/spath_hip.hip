@@ -138,7 +138,7 @@ int repack(sphip_ctx* c, hipStream_t st) {
 	{
 		const uint32_t nblocks = (n + 255) / 256;
 		if ((rc = ensure(c, c->cyl_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cyl_hdr, 256)) ||
-		    (rc = ensure(c, c->cyl_rec, ((size_t)nblocks + 3) * sp::kTile * 32))) return rc;
+		    (rc = ensure(c, c->cyl_rec, ((size_t)n / sp::kCylTile + 4) * sp::kCylTile * 32))) return rc;
 		hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cyl_cnt.p);
 		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cyl_cnt.p, nblocks, (uint32_t*)c->cyl_hdr.p);
 		hipLaunchKernelGGL(sp::k_cyl_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cyl_cnt.p,
