@@ -134,3 +134,70 @@ def test_longest_edge_choice_matches_kernel_rule():
     pick = np.where((l2 >= l1) & (l2 >= lc), 2, np.where(l1 >= lc, 1, 3))
     longest = np.maximum(np.maximum(l1, l2), lc)
     assert np.array_equal(np.where(pick == 2, l2, np.where(pick == 1, l1, lc)), longest)
+
+
+def cyl_records(w, p0, p1):
+    """cyl_record of sp_cyl_scan.h in numpy: w scaled so that its dominant component is exactly 1, each coefficient computed in
+    double and rounded once; H = |h|_2 rounded up.  Returns (class a, beta, gamma, Mc/w_a [n,3], H)."""
+    wd = w.astype(np.float64)
+    wd = wd / np.linalg.norm(wd, axis=1, keepdims=True)
+    aw = np.abs(wd)
+    a = np.where((aw[:, 0] >= aw[:, 1]) & (aw[:, 0] >= aw[:, 2]), 0, np.where(aw[:, 1] >= aw[:, 2], 1, 2))
+    b, c = (a + 1) % 3, (a + 2) % 3
+    idx = np.arange(w.shape[0])
+    s = 1.0 / wd[idx, a]
+    p0d, p1d = p0.astype(np.float64), p1.astype(np.float64)
+    mc = (np.cross(wd, 0.5 * (p0d + p1d)) * s[:, None]).astype(F)
+    hv = np.cross(wd, 0.5 * (p1d - p0d)) * s[:, None]
+    H = (np.sqrt((hv ** 2).sum(1)) * (1.0 + 2.0 ** -20)).astype(F)
+    return a, b, c, (wd[idx, b] * s).astype(F), (wd[idx, c] * s).astype(F), mc, H
+
+
+def test_cylinder_filter_is_conservative_and_implies_the_slab_reject():
+    """Second-generation stage 1 (sp_cyl_scan.h): x = |gm'| - H*D with gm' the axis-normalised 5-term chain.
+      1. it never rejects a pair the strict evaluation accepts;
+      2. wherever it rejects, the slab quantity |gm| - |t| of the first generation (unit w, evaluated in double) exceeds the
+         margin the proof needs (2 x 44u x |dir|(|pos|+|v0|+|v1|+|v2|) covers every slab), i.e. the cylinder's
+         rejections are a subset of the proven slab's with room to spare."""
+    rng = np.random.default_rng(78)
+    n = 400_000
+    pos, d, v0, v1, v2 = make_pairs(rng, n)
+    # half the rays unnormalised: the filter takes |dir| as it comes
+    d = (d * np.where(rng.random((n, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-3, 3, (n, 1)))).astype(F)
+    acc, a_f, sh, vq, e1, e2 = strict(pos, d, v0, v1, v2)
+    assert acc.mean() > 0.2
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    cd = e2d - e1d
+    l1, l2, lc = (e1d ** 2).sum(1), (e2d ** 2).sum(1), (cd ** 2).sum(1)
+    use_u, use_v = (l2 >= l1) & (l2 >= lc), ~((l2 >= l1) & (l2 >= lc)) & (l1 >= lc)
+    w = np.where(use_u[:, None], e2d, np.where(use_v[:, None], e1d, cd))
+    p0 = np.where(use_u[:, None] | use_v[:, None], v0, v1)
+    p1 = np.where(use_u[:, None], v1, np.where(use_v[:, None], v2, v0))
+    a, b, c, beta, gamma, mc, H = cyl_records(w, p0, p1)
+    idx = np.arange(n)
+    P = cross(pos, d)
+    gm = fma(beta, P[idx, b], P[idx, a])
+    gm = fma(gamma, P[idx, c], gm)
+    gm = fma(-d[:, 0], mc[:, 0], gm)
+    gm = fma(-d[:, 1], mc[:, 1], gm)
+    gm = fma(-d[:, 2], mc[:, 2], gm)
+    D = (np.sqrt(((d * d)[:, 0] + (d * d)[:, 1]) + (d * d)[:, 2]).astype(F) * F(1.0 + 2.0 ** -21)).astype(F)
+    x = fma(-H, D, np.abs(gm))
+    d1 = np.abs(d).sum(axis=1).astype(np.float64)
+    p1n = np.abs(pos).sum(axis=1).astype(np.float64)
+    rv = max(np.abs(v).sum(axis=1).max() for v in (v0, v1, v2))
+    Dq = np.maximum((F(2.0 ** -16 * 1.01) * (d1 * (p1n + 2.0 * rv)).astype(F) * F(1.0 + 2.0 ** -20)).astype(F), F(1e-37))
+    reject = ~((x - Dq) < 0) & np.isfinite(x)                  # the kernel keeps a pair iff the sign bit of x - Dq' is set
+    assert not (reject & acc).any(), int((reject & acc).sum())
+    assert 0.01 < reject.mean() < 0.9                       # the pairs are aimed at the triangles: few are rejected, but some are
+    # the slab quantity of the same triangle, unit w, in double
+    wn = w / np.linalg.norm(w, axis=1, keepdims=True)
+    posd, dd = pos.astype(np.float64), d.astype(np.float64)
+    Pd = np.cross(posd, dd)
+    gmu = (wn * Pd).sum(1) - (dd * np.cross(wn, 0.5 * (p0.astype(np.float64) + p1.astype(np.float64)))).sum(1)
+    tu = (dd * np.cross(wn, 0.5 * (p1.astype(np.float64) - p0.astype(np.float64)))).sum(1)
+    mag = np.linalg.norm(dd, axis=1) * (np.linalg.norm(posd, axis=1) + np.linalg.norm(v0.astype(np.float64), axis=1)
+                                         + np.linalg.norm(v1.astype(np.float64), axis=1) + np.linalg.norm(v2.astype(np.float64), axis=1))
+    slack = (np.abs(gmu) - np.abs(tu))[reject] / (U * mag[reject])
+    assert slack.min() > 2 * 44.0, slack.min()                  # needed: 88u; the margin leaves >= 256u/sqrt(3) ~ 148u even for the scaled w
+    print(f"cylinder filter: rejects {reject.mean():.3f}, accepted by the strict test {acc.mean():.3f}; smallest slab slack among its rejections {slack.min():.0f} u (needed 88 u)")
