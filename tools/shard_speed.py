@@ -13,7 +13,7 @@ spp = int(os.environ.get("SPP", "8"))
 for world in (8, 4, 2, 1):
     plan = RowTilePlan(1920, 1080, world, 8)
     sh = ShardedRenderer(ctx, plan, 0, rays, torch.device("cuda"))
-    for var in (6,):
+    for var in (0, 6):
         for rep in range(2):
             sh.render(spp, flags=var); torch.cuda.synchronize(); st = ctx.stats()
         print(f"world {world}: {spp} spp, shard {sh.n} px, variant {var}->{st['kernel_variant']}: {st['kernel_ms']:.1f} ms, {st['scans_executed']*1e4/st['kernel_ms']/1e9:.3f} T tests/s", flush=True)
