@@ -2,7 +2,7 @@
 // default and never what bench.py's headline figure measures, because it changes the work definition: the reference
 // has no acceleration structure (README.md:23) and tests every triangle.
 //
-// Structure: a linear BVH.  Triangles are sorted by the Morton code of their centroid, grouped four to a leaf, and
+// Structure: a linear BVH, built on the device (sp_bvh_build.h).  Triangles are sorted by the Morton code of their centroid, grouped four to a leaf, and
 // the leaves (padded to a power of two) form a complete binary tree in heap order (root 1, children 2i and 2i+1), so
 // parent / sibling / child links are index arithmetic and the tree is refitted bottom-up level by level.
 // Traversal: one ray per lane, stackless with a bit trail (a set bit = "the far child of that level is still to do").
@@ -26,8 +26,9 @@ struct BvhArgs {
 	const int*    leaf_idx;  // original triangle index per sorted triangle, -1 for padding
 	uint32_t n_leaves;       // power of two
 	uint32_t first_leaf;     // == n_leaves (heap index of leaf 0)
-	uint32_t n_big;          // triangles too large for the tree (room walls, ground planes): sorted records [4*n_leaves, 4*n_leaves + n_big)
-	                         // are tested for every ray before the walk, which also gives the walk a tight cull distance from the start
+	const uint32_t* meta;    // device words of the builder (sp_bvh_build.h); meta[8] = n_big: triangles too large for the tree (room walls,
+	                         // ground planes): sorted records [4*n_leaves, 4*n_leaves + n_big) are tested for every ray before the walk,
+	                         // which also gives the walk a tight cull distance from the start
 };
 
 // inclusive slab test; NaNs from 0 * inf drop out because v_min/v_max return the non-NaN operand
@@ -48,7 +49,7 @@ SP_DEV void scan_bvh(const BvhArgs& B, f3 o, f3 dir, int src, float& best_d, int
 	float bd = kMaxDist;
 	int bi = -1;
 	const f3 inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-	for (uint32_t j = 4u * B.n_leaves, e = 4u * B.n_leaves + B.n_big; j < e; ++j) {       // wave-uniform loop: scalar loads
+	for (uint32_t j = 4u * B.n_leaves, e = 4u * B.n_leaves + B.meta[8]; j < e; ++j) {       // wave-uniform loop: scalar loads
 		const int orig = B.leaf_idx[j];
 		const float4 q0 = B.leaf_rec[3 * j], q1 = B.leaf_rec[3 * j + 1], q2 = B.leaf_rec[3 * j + 2];
 		const float d = ray_tri_strict(o, dir, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x));

@@ -10,6 +10,7 @@
 #include "sp_cyl_scan.h"
 #include "sp_scan_kernels.h"
 #include "sp_bvh.h"
+#include "sp_bvh_build.h"
 
 #include <hip/hip_runtime.h>
 
@@ -39,9 +40,9 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, cyl_rec, cyl_cnt, cyl_hdr;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, bvh_sort, bvh_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr;
 	bool bvh_valid = false;
-	uint32_t bvh_leaves = 0, bvh_big = 0;
+	uint32_t bvh_leaves = 0;
 	size_t n_tris = 0;
 	bool have_scene = false;
 	bool have_render = false, timed_upload = false, timed_download = false;
@@ -151,103 +152,40 @@ int repack(sphip_ctx* c, hipStream_t st) {
 	return SPHIP_OK;
 }
 
-// ---- linear BVH for SPHIP_FLAG_ACCEL (sp_bvh.h), built on the host the first time a scene is rendered with the flag
-uint32_t morton10(float x) {   // x in [0,1): spread 10 bits to every third position
-	uint32_t v = (uint32_t)std::min(std::max(x * 1024.0f, 0.0f), 1023.0f);
-	v = (v | (v << 16)) & 0x030000FFu;
-	v = (v | (v << 8)) & 0x0300F00Fu;
-	v = (v | (v << 4)) & 0x030C30C3u;
-	v = (v | (v << 2)) & 0x09249249u;
-	return v;
-}
-
+// ---- linear BVH for SPHIP_FLAG_ACCEL (sp_bvh.h), built on the device (sp_bvh_build.h) the first time a scene is rendered with the flag
 int ensure_bvh(sphip_ctx* c, hipStream_t st) {
 	if (c->bvh_valid) return SPHIP_OK;
-	const size_t n = c->n_tris;
-	std::vector<float> t(n * 12);
-	HIP_TRY(c, hipMemcpyAsync(t.data(), c->tris.p, n * 48, hipMemcpyDeviceToHost, st));
-	HIP_TRY(c, hipStreamSynchronize(st));
-	// scene box and Morton order of the centroids
-	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-	for (size_t i = 0; i < n; ++i)
-		for (int k = 0; k < 9; ++k) { const float v = t[i * 12 + k]; if (std::isfinite(v)) { lo[k % 3] = std::min(lo[k % 3], v); hi[k % 3] = std::max(hi[k % 3], v); } }
-	float ext[3], scale = 0.0f;
-	for (int a = 0; a < 3; ++a) { if (!(hi[a] >= lo[a])) { lo[a] = 0; hi[a] = 0; } ext[a] = hi[a] - lo[a]; scale = std::max(scale, std::max(std::fabs(lo[a]), std::fabs(hi[a]))); }
-	// triangles whose box spans more than a quarter of the scene (walls, ground planes) would put scene-sized boxes on
-	// whole root-to-leaf paths; up to kMaxBig of them (largest first) stay out of the tree and are tested for every ray
-	constexpr size_t kMaxBig = 256;
-	float max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
-	std::vector<std::pair<float, uint32_t>> bigs;
-	std::vector<char> is_big(n, 0);
-	for (size_t i = 0; i < n; ++i) {
-		float e = 0.0f;
-		for (int a = 0; a < 3; ++a) {
-			const float v0 = t[i * 12 + a], v1 = t[i * 12 + 3 + a], v2 = t[i * 12 + 6 + a];
-			e = std::max(e, std::max(v0, std::max(v1, v2)) - std::min(v0, std::min(v1, v2)));
-		}
-		if (!(e <= 0.25f * max_ext)) bigs.push_back({ -e, (uint32_t)i });          // also catches NaN extents
-	}
-	std::sort(bigs.begin(), bigs.end());
-	if (bigs.size() > kMaxBig) bigs.resize(kMaxBig);
-	for (auto& b : bigs) is_big[b.second] = 1;
-	const size_t n_tree = n - bigs.size();
-	std::vector<std::pair<uint32_t, uint32_t>> order;
-	order.reserve(n_tree);
-	for (size_t i = 0; i < n; ++i) {
-		if (is_big[i]) continue;
-		uint32_t code = 0;
-		for (int a = 0; a < 3; ++a) {
-			const float cen = (t[i * 12 + a] + t[i * 12 + 3 + a] + t[i * 12 + 6 + a]) * (1.0f / 3.0f);
-			const float u = ext[a] > 0 ? (cen - lo[a]) / ext[a] : 0.0f;
-			code |= morton10(std::isfinite(u) ? u : 0.0f) << a;
-		}
-		order.push_back({ code, (uint32_t)i });
-	}
-	std::sort(order.begin(), order.end());
-	const uint32_t l0 = (uint32_t)((n_tree + 3) / 4);
+	const uint32_t n = (uint32_t)c->n_tris;
 	uint32_t nl = 1;
-	while (nl < l0) nl <<= 1;
-	std::vector<float> nodes((size_t)2 * nl * 8), rec(((size_t)nl * 4 + bigs.size()) * 12, 0.0f);
-	std::vector<int> idx((size_t)nl * 4 + bigs.size(), -1);
-	auto box = [&](uint32_t node) { return &nodes[(size_t)node * 8]; };   // lo.xyz hi.x | hi.yz pad pad
-	for (uint32_t node = 0; node < 2 * nl; ++node) { float* b = box(node); b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY; b[6] = b[7] = 0; }
-	auto put_record = [&](size_t j, uint32_t i) {
-		const float* s = &t[(size_t)i * 12];
-		float* r = &rec[j * 12];
-		r[0] = s[0]; r[1] = s[1]; r[2] = s[2];
-		r[3] = s[3] - s[0]; r[4] = s[4] - s[1]; r[5] = s[5] - s[2];      // e1, e2: the reference's float subtractions (geom.h:200-201)
-		r[6] = s[6] - s[0]; r[7] = s[7] - s[1]; r[8] = s[8] - s[2];
-		idx[j] = (int)i;
-	};
-	for (size_t j = 0; j < n_tree; ++j) {
-		const uint32_t i = order[j].second;
-		put_record(j, i);
-		const float* s = &t[(size_t)i * 12];
-		float* b = box(nl + (uint32_t)(j / 4));
-		for (int k = 0; k < 9; ++k) { const float v = s[k]; if (std::isfinite(v)) { b[k % 3] = std::min(b[k % 3], v); b[3 + k % 3] = std::max(b[3 + k % 3], v); } }
-	}
-	for (size_t k = 0; k < bigs.size(); ++k) put_record((size_t)nl * 4 + k, bigs[k].second);
-	// inflate the leaves (the slab test runs in float: keep every geometric hit inside), then refit bottom-up
-	for (uint32_t leaf = nl; leaf < 2 * nl; ++leaf) {
-		float* b = box(leaf);
-		if (!(b[3] >= b[0])) continue;                    // empty (padding) leaf: inverted box, never entered
-		for (int a = 0; a < 3; ++a) {
-			const float pad = 1e-5f * std::max(std::max(std::fabs(b[a]), std::fabs(b[3 + a])), b[3 + a] - b[a]) + 1e-6f * scale + 1e-30f;
-			b[a] -= pad; b[3 + a] += pad;
-		}
-	}
-	for (uint32_t node = nl - 1; node >= 1; --node) {
-		float* b = box(node); const float* l = box(2 * node); const float* r = box(2 * node + 1);
-		for (int a = 0; a < 3; ++a) { b[a] = std::min(l[a], r[a]); b[3 + a] = std::max(l[3 + a], r[3 + a]); }
-	}
+	while ((uint64_t)nl * 4 < n) nl <<= 1;                 // leaves of 4 triangles, padded to a power of two (complete tree in heap order)
+	const uint32_t nblocks = (n + 255) / 256, rs_blocks = (n + sp::kRsPerBlock - 1) / sp::kRsPerBlock;
 	int rc;
-	if ((rc = ensure(c, c->bvh_nodes, nodes.size() * 4)) || (rc = ensure(c, c->bvh_rec, rec.size() * 4)) || (rc = ensure(c, c->bvh_idx, idx.size() * 4))) return rc;
-	HIP_TRY(c, hipMemcpyAsync(c->bvh_nodes.p, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice, st));
-	HIP_TRY(c, hipMemcpyAsync(c->bvh_rec.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, st));
-	HIP_TRY(c, hipMemcpyAsync(c->bvh_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
-	HIP_TRY(c, hipStreamSynchronize(st));          // the staging vectors die with this call
+	if ((rc = ensure(c, c->bvh_nodes, (size_t)2 * nl * 32)) || (rc = ensure(c, c->bvh_rec, ((size_t)nl * 4 + sp::kBvhMaxBig) * 48)) ||
+	    (rc = ensure(c, c->bvh_idx, ((size_t)nl * 4 + sp::kBvhMaxBig) * 4)) || (rc = ensure(c, c->bvh_sort, (size_t)n * 16)) ||
+	    (rc = ensure(c, c->bvh_hist, (size_t)rs_blocks * 16 * 4)) || (rc = ensure(c, c->bvh_meta, 256))) return rc;
+	uint32_t* meta = (uint32_t*)c->bvh_meta.p;
+	uint32_t* keys[2] = { (uint32_t*)c->bvh_sort.p, (uint32_t*)c->bvh_sort.p + (size_t)n };
+	uint32_t* vals[2] = { (uint32_t*)c->bvh_sort.p + (size_t)2 * n, (uint32_t*)c->bvh_sort.p + (size_t)3 * n };
+	const float* tris = (const float*)c->tris.p;
+	const dim3 b256(256);
+	hipLaunchKernelGGL(sp::k_bvh_meta_init, dim3(1), b256, 0, st, meta);
+	hipLaunchKernelGGL(sp::k_bvh_box, dim3(nblocks), b256, 0, st, tris, n, meta);
+	hipLaunchKernelGGL(sp::k_bvh_count_big, dim3(nblocks), b256, 0, st, tris, n, meta);
+	hipLaunchKernelGGL(sp::k_bvh_keys, dim3(nblocks), b256, 0, st, tris, n, meta, keys[0], vals[0]);
+	int cur = 0;
+	for (uint32_t shift = 0; shift < 32; shift += 4, cur ^= 1) {       // stable LSD radix sort by (Morton code; big triangles last)
+		hipLaunchKernelGGL(sp::k_rs_hist, dim3(rs_blocks), b256, 0, st, (const uint32_t*)keys[cur], n, shift, rs_blocks, (uint32_t*)c->bvh_hist.p);
+		hipLaunchKernelGGL(sp::k_rs_scan, dim3(1), b256, 0, st, (uint32_t*)c->bvh_hist.p, rs_blocks * 16u);
+		hipLaunchKernelGGL(sp::k_rs_scatter, dim3(rs_blocks), b256, 0, st, (const uint32_t*)keys[cur], (const uint32_t*)vals[cur], n, shift, rs_blocks,
+		                   (const uint32_t*)c->bvh_hist.p, keys[cur ^ 1], vals[cur ^ 1]);
+	}
+	hipLaunchKernelGGL(sp::k_bvh_leaves, dim3((nl + 255) / 256), b256, 0, st, tris, n, (const uint32_t*)meta, (const uint32_t*)vals[cur], nl,
+	                   (float4*)c->bvh_nodes.p, (float4*)c->bvh_rec.p, (int*)c->bvh_idx.p);
+	hipLaunchKernelGGL(sp::k_bvh_bigs, dim3(1), b256, 0, st, tris, n, (const uint32_t*)meta, (const uint32_t*)vals[cur], nl, (float4*)c->bvh_rec.p, (int*)c->bvh_idx.p);
+	for (uint32_t first = nl >> 1; first >= 1; first >>= 1)              // bottom-up, one level per launch
+		hipLaunchKernelGGL(sp::k_bvh_refit, dim3((first + 255) / 256), b256, 0, st, (float4*)c->bvh_nodes.p, first);
+	HIP_TRY(c, hipGetLastError());
 	c->bvh_leaves = nl;
-	c->bvh_big = (uint32_t)bigs.size();
 	c->bvh_valid = true;
 	return SPHIP_OK;
 }
@@ -351,7 +289,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	if (variant == kVariantAccel) {
 		if ((rc = ensure_bvh(c, st))) return rc;
 		B.nodes = (const float4*)c->bvh_nodes.p; B.leaf_rec = (const float4*)c->bvh_rec.p; B.leaf_idx = (const int*)c->bvh_idx.p;
-		B.n_leaves = c->bvh_leaves; B.first_leaf = c->bvh_leaves; B.n_big = c->bvh_big;
+		B.n_leaves = c->bvh_leaves; B.first_leaf = c->bvh_leaves; B.meta = (const uint32_t*)c->bvh_meta.p;
 	}
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
 	if (variant == kVariantAccel) {
@@ -777,8 +715,8 @@ void sphip_destroy(sphip_t* c) {
 	}
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[17] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
-	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr };
+	DevBuf* bufs[20] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->bvh_sort, &c->bvh_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
