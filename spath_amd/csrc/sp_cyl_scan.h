@@ -199,20 +199,9 @@ struct CylRay {            // per-slot filter state
 	float D[R], Dq[R];             // |dir|_2 rounded up; margin (sp_filter_scan.h) a hair above, or +-inf
 };
 
-// Closest hit for the R rays of every lane.  Block-uniform call (barriers inside).
+// per-slot filter state of the R rays of a lane (shared by scan_cyl and scan_cylw)
 template <int R>
-SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
-	__shared__ float4 sm[2 * kCylTileQ];
-	static_assert(R == 1 || R == 2 || R == 4, "bits per group must divide 32");
-	constexpr uint32_t kGPW = 32u / R;                 // groups of 4 triangles per 32-bit word
-	constexpr int kNW = (int)((kCylTile / 4u) / kGPW);   // words per tile
-	// the tile's bit words, [word][thread]: written once per word by the hot loop, read back by stage 2 when a lane moves on to
-	// its next non-empty word (in registers they would have to be picked and cleared through select cascades)
-	__shared__ uint32_t wq[kNW * 256];
-	const uint32_t tid = threadIdx.x;
-	const uint32_t wbase = tid & ~63u;
-
-	CylRay<R> f;
+SP_DEV void cyl_setup(float rv, const RaySlots<R>& s, CylRay<R>& f) {
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
 		const f3 P = cross3(s.o[r], s.dir[r]);
@@ -232,9 +221,26 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 		// survive <=> !(x > Dq); tested as sign(x - Dq') with Dq' a hair above Dq (and > 0), so that x == Dq survives too
 		const float dq = fmaxf(0x1p-16f * 1.01f * mag * (1.0f + 0x1p-20f), 1e-37f);
 		f.Dq[r] = !s.act[r] ? -__builtin_inff() : (fin ? dq : __builtin_inff());     // inactive slot: x - (-inf) = +inf, rejected
-		bd[r] = kMaxDist;
-		bi[r] = -1;
 	}
+}
+
+// Closest hit for the R rays of every lane.  Block-uniform call (barriers inside).
+template <int R>
+SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
+	__shared__ float4 sm[2 * kCylTileQ];
+	static_assert(R == 1 || R == 2 || R == 4, "bits per group must divide 32");
+	constexpr uint32_t kGPW = 32u / R;                 // groups of 4 triangles per 32-bit word
+	constexpr int kNW = (int)((kCylTile / 4u) / kGPW);   // words per tile
+	// the tile's bit words, [word][thread]: written once per word by the hot loop, read back by stage 2 when a lane moves on to
+	// its next non-empty word (in registers they would have to be picked and cleared through select cascades)
+	__shared__ uint32_t wq[kNW * 256];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t wbase = tid & ~63u;
+
+	CylRay<R> f;
+	cyl_setup<R>(rv, s, f);
+#pragma unroll
+	for (int r = 0; r < R; ++r) { bd[r] = kMaxDist; bi[r] = -1; }
 
 	// the stream is one run of tiles: class 0's, then class 1's, then class 2's (each class starts on a tile boundary)
 	const uint32_t total_tiles = cs.hdr[6];
@@ -361,6 +367,169 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 		}
 #endif
 		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// scan_cylw: the same stage 1, stage 2 shared by the whole WAVE.
+//
+// In scan_cyl a lane resolves only its own set bits, so a tile's stage 2 lasts as long as the busiest lane needs: 18 rounds per
+// 384-triangle tile with 42 % of the lanes working (profiles/filter_stats.json).  Here the set bits of one slot (ray r of every
+// lane) are written out as a list of (lane, group) entries in LDS, and ALL 64 lanes take entries from that list, 64 per round:
+//   * the bit words are kept per slot (a group's R sign bits go to R different words: same one instruction per pair), so a
+//     slot's bits need no de-interleaving;
+//   * the entry's ray is the donor lane's slot-r registers, a FIXED register set for the whole round: twelve ds_bpermute_b32;
+//   * the result goes back through one 64-bit LDS atomicMin per hit on the key (float bits of d) << 32 | index -- d > 0, so keys
+//     order like (d, index) pairs: the closest hit with the lowest index on ties, i.e. the reference's "ascending index, first
+//     strictly smaller d wins" (cpu_renderer.cpp:39-49) in any processing order.  The running best of every ray lives in that
+//     cell for the whole scan.
+// A wave lists at most kCylCap entries per pass (16 bits each); what does not fit waits in the words for the next pass (rare).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kCylCap = 64u * 12u;      // list entries per wave and pass (16 bits each): 12 per lane on average
+
+template <int R>
+SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
+	__shared__ float4 sm[2 * kCylTileQ];
+	__shared__ unsigned short lst[4 * kCylCap];               // per wave: (donor lane << 7) | group within the tile
+	__shared__ uint32_t lcnt[4];                              // per wave: entries listed in the current pass
+	static_assert(kCylTile / 4u <= 128u, "group index must fit 7 bits");
+	__shared__ unsigned long long cell[R * 256];              // per (slot, thread): best (d bits << 32 | index) so far
+	constexpr int kW = (int)(kCylTile / 128u);                // 32-bit words per slot and tile (one bit per group of 4 triangles)
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+	unsigned short* const mylst = lst + (tid >> 6) * kCylCap;
+	uint32_t* const mycnt = lcnt + (tid >> 6);
+
+	CylRay<R> f;
+	cyl_setup<R>(rv, s, f);
+	const unsigned long long kNone = ((unsigned long long)__float_as_uint(kMaxDist) << 32) | 0xffffffffull;
+#pragma unroll
+	for (int r = 0; r < R; ++r) cell[r * 256 + tid] = kNone;
+
+	const uint32_t total_tiles = cs.hdr[6];
+	uint32_t cls = 0;
+	__syncthreads();                                  // readers of the previous scan are done with sm
+	cyl_tile_dma(cs.rec, sm, tid, wbase);
+	__syncthreads();                                  // (the barrier's fence waits for the DMA: vmcnt(0))
+	for (uint32_t gt = 0; gt < total_tiles; ++gt) {
+		while (cls < 2u && gt >= cs.hdr[4 + cls]) {
+#pragma unroll
+			for (int r = 0; r < R; ++r) { const float t0 = f.Pa[r]; f.Pa[r] = f.Pb[r]; f.Pb[r] = f.Pc[r]; f.Pc[r] = t0; }
+			++cls;
+		}
+		const float4* cur = sm + (gt & 1u) * kCylTileQ;
+		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kCylTile;
+		const uint32_t ngroups = ((left < kCylTile ? left : kCylTile) + 3u) / 4u;
+		// ---- stage 1: word[r][wi] bit (31 - k) = group 32*wi + k of this tile survives for ray r
+		uint32_t word[R][kW];
+		uint32_t g = 0;
+#pragma unroll
+		for (int wi = 0; wi < kW; ++wi) {
+			uint32_t wv[R];
+#pragma unroll
+			for (int r = 0; r < R; ++r) wv[r] = 0;
+			const uint32_t gend = ngroups < (uint32_t)(wi + 1) * 32u ? ngroups : (uint32_t)(wi + 1) * 32u;
+			const uint32_t g0 = g;
+			for (; g < gend; ++g) {
+				float4 a0[4], a1[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { a0[u] = cur[g * 8u + 2 * u]; a1[u] = cur[g * 8u + 2 * u + 1]; }
+#pragma unroll
+				for (int r = 0; r < R; ++r) {
+					float x[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) x[u] = cyl_x(a0[u], a1[u], f.Pa[r], f.Pb[r], f.Pc[r], f.ndx[r], f.ndy[r], f.ndz[r], f.D[r]);
+					const float m = __builtin_fminf(__builtin_fminf(x[0], x[1]), __builtin_fminf(x[2], x[3]));
+					wv[r] = __builtin_amdgcn_alignbit(wv[r], __float_as_uint(m - f.Dq[r]), 31);      // (wv << 1) | sign(m - Dq)
+				}
+			}
+			const uint32_t done = g - g0;                             // bits appended; left-align (wave-uniform shift)
+#pragma unroll
+			for (int r = 0; r < R; ++r) word[r][wi] = done == 0u ? 0u : (wv[r] << (32u - done));
+		}
+		// the next tile streams in while the survivors are resolved
+		if (gt + 1u < total_tiles) cyl_tile_dma(cs.rec + (size_t)(gt + 1u) * kCylTileQ, sm + ((gt + 1u) & 1u) * kCylTileQ, tid, wbase);
+		// ---- stage 2, slot by slot
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			for (;;) {                                                // passes: one, unless the wave's list overflows
+				uint32_t c = 0;
+#pragma unroll
+				for (int wi = 0; wi < kW; ++wi) c += (uint32_t)__builtin_popcount(word[r][wi]);
+				if (!__any(c != 0u)) break;
+				// list space: one LDS atomic per lane (any disjoint allocation will do: the results meet in an order-independent atomicMin)
+				if (lane == 0) *mycnt = 0u;
+				uint32_t j = c ? atomicAdd(mycnt, c) : 0u;
+				const uint32_t jend = j + c < kCylCap ? j + c : kCylCap;     // what does not fit stays in the words for the next pass
+#pragma unroll
+				for (int wi = 0; wi < kW; ++wi) {
+					uint32_t m = word[r][wi];
+					while (__any(m != 0u && j < jend)) {
+						if (m != 0u && j < jend) {
+							const uint32_t e = (uint32_t)__builtin_clz(m);
+							mylst[j++] = (unsigned short)((lane << 7) | ((uint32_t)wi * 32u + e));
+							m &= ~(0x80000000u >> e);
+						}
+					}
+					word[r][wi] = m;
+				}
+				uint32_t total = *mycnt;
+				total = (uint32_t)__builtin_amdgcn_readfirstlane((int)(total < kCylCap ? total : kCylCap));
+#ifdef SP_FILTER_STATS
+				if (lane == 0) { atomicAdd(a.scans + 1, (unsigned long long)total); atomicAdd(a.scans + 2, (unsigned long long)((total + 63u) / 64u)); }
+#endif
+				// rounds: 64 entries at a time, one per lane
+				for (uint32_t base = 0; base < total; base += 64u) {
+					const uint32_t ent = base + lane;
+					const bool ok = ent < total;
+					const uint32_t entry = mylst[ok ? ent : 0u];
+					const int L = (int)(entry >> 7);
+					const uint32_t grp = entry & 127u;
+					// the donor's ray r: a fixed register set, fetched across lanes (every lane takes part in the permutes)
+					const float ox = __shfl(s.o[r].x, L, 64), oy = __shfl(s.o[r].y, L, 64), oz = __shfl(s.o[r].z, L, 64);
+					const float dx = __shfl(s.dir[r].x, L, 64), dy = __shfl(s.dir[r].y, L, 64), dz = __shfl(s.dir[r].z, L, 64);
+					const int src = __shfl(s.src[r], L, 64);
+					const float Pa = __shfl(f.Pa[r], L, 64), Pb = __shfl(f.Pb[r], L, 64), Pc = __shfl(f.Pc[r], L, 64);
+					const float D = __shfl(f.D[r], L, 64), Dq = __shfl(f.Dq[r], L, 64);
+					// (a ray whose filter is off has a zero moment and Dq = +inf: it survives whatever x comes out, so -dir serves for all)
+					// the group's four records and their x again: which of the four survive
+					uint32_t cand = 0;
+					int idx4[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const float4 q0 = cur[grp * 8u + 2 * u], q1 = cur[grp * 8u + 2 * u + 1];
+						const float x = cyl_x(q0, q1, Pa, Pb, Pc, -dx, -dy, -dz, D);
+						cand |= (ok && !(x - Dq >= 0.0f)) ? (1u << u) : 0u;          // the sign-bit decision again; NaN -> survivor
+						idx4[u] = (int)__float_as_uint(q1.z);
+					}
+					while (__any(cand != 0u)) {                               // one exact test per lane and turn (1.09 per entry on average)
+						if (cand != 0u) {
+							const uint32_t low = cand & (0u - cand);
+							cand ^= low;
+							const int idx = (low & 1u) ? idx4[0] : (low & 2u) ? idx4[1] : (low & 4u) ? idx4[2] : idx4[3];
+#ifdef SP_FILTER_STATS
+							atomicAdd(a.scans + 4, 1ull);
+#endif
+							const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
+							const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+							// cpu_renderer.cpp:44: cur_d > 0 && cur_d < d, d starting at MAX_VALUE_DIST; ties -> lowest index: the key's low word
+							if ((d > 0.0f) && (d < kMaxDist) && (idx != src))
+								atomicMin(&cell[r * 256 + (int)wbase + L], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)idx);
+						}
+					}
+				}
+			}
+		}
+#ifdef SP_FILTER_STATS
+		if (lane == 0) atomicAdd(a.scans + 3, 1ull);
+#endif
+		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
+	}
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const unsigned long long k = cell[r * 256 + tid];
+		bd[r] = __uint_as_float((uint32_t)(k >> 32));
+		bi[r] = (int)(uint32_t)k;                          // 0xffffffff = -1: no hit
 	}
 }
 

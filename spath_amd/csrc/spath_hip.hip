@@ -91,18 +91,18 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 
 // kernel variants selectable through the low byte of `flags` (sphip_kernel_name); all brute force except 8
 constexpr int kVariantAccel = 8;          // the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
-constexpr int kVariantLast = 13;
+constexpr int kVariantLast = 15;
 constexpr uint64_t kChunkTargetBlocks = 262144;         // 256 x the 1024 resident workgroups (measured: profiles/r01_sample_chunks.log)
 constexpr uint64_t kChunkMaxBytes = 16ull << 30;         // cap of the per-sample scratch buffer
 const char* const kVariantNames[kVariantLast + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
-                                                      "accel_lbvh", "rpl_cyl1", "rpl_cyl2", "rpl_cyl4", "rpl_cyl2s", "rpl_cyl4s" };
+                                                      "accel_lbvh", "rpl_cyl1", "rpl_cyl2", "rpl_cyl4", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4", "rpl_cylw4s" };
 
 // the two-stage scan variants: paths per lane (R), whether the R paths are consecutive samples of ONE pixel (split) or R
 // pixels, and the scan generation (0 = slab filter + LDS queues, sp_filter_scan.h; 1 = cylinder filter + bit words, sp_cyl_scan.h)
 struct TwoStage { int R; bool split; int scan; };
 bool two_stage(int variant, TwoStage* out) {
 	static const TwoStage tab[kVariantLast + 1] = { {0, false, 0}, {0, false, 0}, {0, false, 0}, {2, false, 0}, {4, false, 0}, {1, false, 0}, {2, true, 0}, {4, true, 0},
-	                                                {0, false, 0}, {1, false, 1}, {2, false, 1}, {4, false, 1}, {2, true, 1}, {4, true, 1} };
+	                                                {0, false, 0}, {1, false, 1}, {2, false, 1}, {4, false, 1}, {2, true, 1}, {4, true, 1}, {4, false, 2}, {4, true, 2} };
 	if (variant < 0 || variant > kVariantLast || tab[variant].R == 0) return false;
 	if (out) *out = tab[variant];
 	return true;
@@ -116,9 +116,10 @@ int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_sam
 	// Path tracing with >= 2 spp: consecutive SAMPLES of a pixel share a lane (a record read from LDS serves all of them; a
 	// workgroup still covers 256 pixels, and sample chunks (launch_render) supply the workgroups a small frame lacks).
 	// One scan per ray (flat pass, 1 spp): pixels share a lane when that still leaves >= ~768 workgroups.
-	if (mode == SPHIP_MODE_PT && n_samples >= 4) return 13;
+	// Four paths per lane run the wave-shared stage 2 (sp_cyl_scan.h: scan_cylw), fewer the per-lane one.
+	if (mode == SPHIP_MODE_PT && n_samples >= 4) return 15;
 	if (mode == SPHIP_MODE_PT && n_samples >= 2) return 12;
-	return n_rays >= 768u * 1024u ? 11 : (n_rays >= 384u * 1024u ? 10 : 9);
+	return n_rays >= 768u * 1024u ? 14 : (n_rays >= 384u * 1024u ? 10 : 9);
 }
 
 int repack(sphip_ctx* c, hipStream_t st) {
@@ -301,6 +302,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		if (is_ts) {
 #define SP_HIT(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd, d_src, oi, od)
 			if (ts.scan == 0) { if (ts.R == 4) SP_HIT(4, 0); else if (ts.R == 2) SP_HIT(2, 0); else SP_HIT(1, 0); }
+			else if (ts.scan == 2) SP_HIT(4, 2);
 			else              { if (ts.R == 4) SP_HIT(4, 1); else if (ts.R == 2) SP_HIT(2, 1); else SP_HIT(1, 1); }
 #undef SP_HIT
 		}
@@ -310,6 +312,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		if (is_ts) {
 #define SP_FLAT(R_, S_) hipLaunchKernelGGL((sp::k_flat_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd)
 			if (ts.scan == 0) { if (ts.R == 4) SP_FLAT(4, 0); else if (ts.R == 2) SP_FLAT(2, 0); else SP_FLAT(1, 0); }
+			else if (ts.scan == 2) SP_FLAT(4, 2);
 			else              { if (ts.R == 4) SP_FLAT(4, 1); else if (ts.R == 2) SP_FLAT(2, 1); else SP_FLAT(1, 1); }
 #undef SP_FLAT
 		}
@@ -321,6 +324,8 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 			if (ts.scan == 0) {
 				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 0); else SP_PT(2, true, 0); }
 				else          { if (ts.R == 4) SP_PT(4, false, 0); else if (ts.R == 2) SP_PT(2, false, 0); else SP_PT(1, false, 0); }
+			} else if (ts.scan == 2) {
+				if (ts.split) SP_PT(4, true, 2); else SP_PT(4, false, 2);
 			} else {
 				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 1); else SP_PT(2, true, 1); }
 				else          { if (ts.R == 4) SP_PT(4, false, 1); else if (ts.R == 2) SP_PT(2, false, 1); else SP_PT(1, false, 1); }

@@ -6,7 +6,7 @@ import numpy as np, torch
 from spath_amd import capi, scene, view
 from oracle import oracle as O
 
-NEW = [9, 10, 11, 12, 13]
+NEW = [9, 10, 11, 12, 13, 14, 15]
 names = {v: k for k, v in capi.kernel_variants().items()}
 ctx = capi.Context(0)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -67,7 +67,7 @@ if len(sys.argv) < 2:
     ctx.set_scene_device(d_t.data_ptr(), d_m.data_ptr(), t.shape[0], 0)
     out = torch.zeros(w * h, 4, dtype=torch.uint8, device="cuda")
     ref = None
-    for var in [6, 12, 13, 10, 9]:
+    for var in [6, 13, 15, 14]:
         best = 1e9
         for rep in range(2):
             ctx.render_device(d_r.data_ptr(), w * h, spp, out.data_ptr(), flags=var)
