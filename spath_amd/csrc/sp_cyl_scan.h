@@ -27,7 +27,7 @@
 // four records (per-lane LDS addresses), recomputes the four x, and runs ray_tri_strict on each survivor.  There is no
 // queue, hence no overflow: a scene of huge triangles degrades smoothly to the exact-only scan.
 //
-// record: 32 B = 2 x float4 (class a, with (a,b,c) a cyclic rotation of (x,y,z)):
+// record: 32 B = 2 x float4 (class a, with (a,b,c) a cyclic rotation of (x,y,z)); tiles are stored chunk-major (cyl_slot):
 //   q0 = w_b/w_a  w_c/w_a  Mc.x/w_a  Mc.y/w_a        q1 = Mc.z/w_a  H/|w_a|  bits(original index)  0
 #pragma once
 
@@ -46,6 +46,13 @@ namespace sp {
 constexpr uint32_t kCylTile = SP_CYL_TILE;
 static_assert(kCylTile % 128 == 0, "whole waves per LDS-DMA pass, whole words of group bits");
 constexpr uint32_t kCylTileQ = 2u * kCylTile;     // float4 per tile
+constexpr uint32_t kCylGroups = kCylTile / 4u;    // groups of 4 triangles per tile
+// A tile is stored CHUNK-MAJOR, in the global stream and in LDS alike: float4 number c (0..7: records 0..3 of a group, two float4
+// each) of group g sits at position c * kCylGroups + g.  Stage 1 reads a group at a wave-uniform g (broadcast reads with immediate
+// offsets c * kCylGroups * 16 B); stage 2 reads at a PER-LANE group, and then consecutive groups are consecutive 16-B slots --
+// 16 bank phases.  With the records of a group contiguous (g * 128 B + const) every lane of an instruction would fall on one of
+// two bank phases: ~32-way conflicts, a third of all LDS cycles (profiles/r02_pmc_per_lane_vs_wave_shared_stage2_spp16.txt).
+SP_DEV constexpr uint32_t cyl_slot(uint32_t group, uint32_t chunk) { return chunk * kCylGroups + group; }
 
 struct CylStream {
 	const float4* rec;       // class-major stream; every class starts on a tile boundary
@@ -155,8 +162,10 @@ __global__ void __launch_bounds__(256) k_cyl_scatter(const float* __restrict__ t
 	if (cls >= 0) {
 		for (uint32_t v = 0; v < wv; ++v) rank += wave_cnt[v][cls];
 		const size_t pos = (size_t)hdr[3 + cls] * kCylTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
-		rec[pos * 2 + 0] = q0;
-		rec[pos * 2 + 1] = q1;
+		const size_t tile = pos / kCylTile;
+		const uint32_t in_tile = (uint32_t)(pos - tile * kCylTile), grp = in_tile >> 2, u = in_tile & 3u;
+		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u)] = q0;
+		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u + 1u)] = q1;
 	}
 }
 
@@ -167,8 +176,10 @@ __global__ void __launch_bounds__(256) k_cyl_pad(const uint32_t* __restrict__ hd
 	const uint32_t k = blockIdx.x, tid = threadIdx.x;
 	const uint32_t n = hdr[k], first = hdr[3 + k] * kCylTile;
 	for (uint32_t pos = n + tid; pos < (n + kCylTile - 1u) / kCylTile * kCylTile; pos += 256u) {
-		rec[((size_t)first + pos) * 2 + 0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		rec[((size_t)first + pos) * 2 + 1] = make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f);
+		const size_t gpos = (size_t)first + pos, tile = gpos / kCylTile;
+		const uint32_t in_tile = (uint32_t)(gpos - tile * kCylTile), grp = in_tile >> 2, u = in_tile & 3u;
+		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u + 1u)] = make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f);
 	}
 }
 
@@ -269,7 +280,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 			for (; g < gend; ++g) {
 				float4 a0[4], a1[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { a0[u] = cur[g * 8u + 2 * u]; a1[u] = cur[g * 8u + 2 * u + 1]; }
+				for (int u = 0; u < 4; ++u) { a0[u] = cur[cyl_slot(g, 2 * u)]; a1[u] = cur[cyl_slot(g, 2 * u + 1)]; }
 #pragma unroll
 				for (int r = 0; r < R; ++r) {
 					float x[4];
@@ -330,7 +341,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 				uint32_t cand = 0; int idx = 0;
 #pragma unroll
 				for (int u = 3; u >= 0; --u) {
-					const float4 q0 = cur[grp * 8u + 2 * u], q1 = cur[grp * 8u + 2 * u + 1];
+					const float4 q0 = cur[cyl_slot(grp, 2 * u)], q1 = cur[cyl_slot(grp, 2 * u + 1)];
 					const float x = cyl_x(q0, q1, Pa, Pb, Pc, ndx, ndy, ndz, D);
 					const bool sv = !(x - Dq >= 0.0f) && !((sub >> u) & 1u);      // the sign-bit decision again; NaN -> survivor
 					cand = sv ? (cand | (1u << u)) : cand;
@@ -433,7 +444,7 @@ SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			for (; g < gend; ++g) {
 				float4 a0[4], a1[4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { a0[u] = cur[g * 8u + 2 * u]; a1[u] = cur[g * 8u + 2 * u + 1]; }
+				for (int u = 0; u < 4; ++u) { a0[u] = cur[cyl_slot(g, 2 * u)]; a1[u] = cur[cyl_slot(g, 2 * u + 1)]; }
 #pragma unroll
 				for (int r = 0; r < R; ++r) {
 					float x[4];
@@ -497,7 +508,7 @@ SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlo
 					int idx4[4];
 #pragma unroll
 					for (int u = 0; u < 4; ++u) {
-						const float4 q0 = cur[grp * 8u + 2 * u], q1 = cur[grp * 8u + 2 * u + 1];
+						const float4 q0 = cur[cyl_slot(grp, 2 * u)], q1 = cur[cyl_slot(grp, 2 * u + 1)];
 						const float x = cyl_x(q0, q1, Pa, Pb, Pc, -dx, -dy, -dz, D);
 						cand |= (ok && !(x - Dq >= 0.0f)) ? (1u << u) : 0u;          // the sign-bit decision again; NaN -> survivor
 						idx4[u] = (int)__float_as_uint(q1.z);
