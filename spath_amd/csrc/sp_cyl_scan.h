@@ -493,7 +493,7 @@ SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				for (uint32_t base = 0; base < total; base += 64u) {
 					const uint32_t ent = base + lane;
 					const bool ok = ent < total;
-					const uint32_t entry = mylst[ok ? ent : 0u];
+					const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 7);       // idle lanes: their own ray, group 0, result discarded
 					const int L = (int)(entry >> 7);
 					const uint32_t grp = entry & 127u;
 					// the donor's ray r: a fixed register set, fetched across lanes (every lane takes part in the permutes)
