@@ -505,9 +505,26 @@ int multi_render(sphip_ctx* c, const float* rays, const sphip_camera* cam, size_
 		if (rcs[(size_t)r]) return fail(c, rcs[(size_t)r], "device %d: %s", c->kids[(size_t)r]->device, c->kids[(size_t)r]->err.c_str());
 	HIP_TRY(c, hipSetDevice(root->device));
 	hipStream_t rs = root->own_stream;
-	if (peer) {
-		for (int r = 1; r < g; ++r) if (plan.n_rays(r)) HIP_TRY(c, hipStreamWaitEvent(rs, c->ev_tile[(size_t)r], 0));
-	} else {
+	// peer-copy exchange, issued from this thread: device r's tiles -> slot r of the first device's buffer, in stream order behind its
+	// kernels (the host threads do the same themselves when peer copies are the context's exchange from the start)
+	auto gather_peer_now = [&]() -> int {
+		for (int r = 0; r < g; ++r) {
+			const size_t n = plan.n_rays(r);
+			if (!n) continue;
+			sphip_ctx* k = c->kids[(size_t)r];
+			HIP_TRY(c, hipSetDevice(k->device));
+			const bool same = k->device == root->device;
+			if (same) HIP_TRY(c, hipMemcpyAsync((char*)c->gath.p + (size_t)r * pad * 4, k->rgba.p, n * 4, hipMemcpyDeviceToDevice, k->own_stream));
+			else HIP_TRY(c, hipMemcpyPeerAsync((char*)c->gath.p + (size_t)r * pad * 4, root->device, k->rgba.p, k->device, n * 4, k->own_stream));
+			if (out_accum && same) HIP_TRY(c, hipMemcpyAsync((char*)c->gath_acc.p + (size_t)r * pad * 12, k->accum.p, n * 12, hipMemcpyDeviceToDevice, k->own_stream));
+			else if (out_accum) HIP_TRY(c, hipMemcpyPeerAsync((char*)c->gath_acc.p + (size_t)r * pad * 12, root->device, k->accum.p, k->device, n * 12, k->own_stream));
+			HIP_TRY(c, hipEventRecord(c->ev_tile[(size_t)r], k->own_stream));
+		}
+		HIP_TRY(c, hipSetDevice(root->device));
+		return SPHIP_OK;
+	};
+	bool wait_tiles = peer;
+	if (!peer) {
 		// one grouped exchange: every other device sends its tiles, the first device receives them into its gather buffer;
 		// its own tiles are a local copy
 		if (plan.n_rays(0)) {
@@ -525,8 +542,17 @@ int multi_render(sphip_ctx* c, const float* rays, const sphip_camera* cam, size_
 			if (out_accum && !nrc) nrc = g_rccl.recv((char*)c->gath_acc.p + (size_t)r * pad * 12, n * 12, kNcclUint8, r, c->comms[0], rs);
 		}
 		const int erc = g_rccl.group_end();
-		if (nrc || erc) return fail(c, SPHIP_E_DEVICE, "RCCL gather failed: %s", g_rccl.errstr ? g_rccl.errstr(nrc ? nrc : erc) : "?");
+		if (nrc || erc) {
+			// the communicator did not take the exchange: this frame and every later one go through peer copies (the kernels'
+			// results are still in each device's buffer); say so once, loudly
+			fprintf(stderr, "libspath_hip: RCCL gather failed (%s); falling back to peer copies\n", g_rccl.errstr ? g_rccl.errstr(nrc ? nrc : erc) : "?");
+			c->gather_kind = SPHIP_GATHER_PEER;
+			if ((rc = gather_peer_now())) return rc;
+			wait_tiles = true;
+		}
 	}
+	if (wait_tiles)
+		for (int r = 1; r < g; ++r) if (plan.n_rays(r)) HIP_TRY(c, hipStreamWaitEvent(rs, c->ev_tile[(size_t)r], 0));
 	const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
 	hipLaunchKernelGGL(sp::k_assemble<1>, grid, block, 0, rs, (const uint32_t*)c->gath.p, (uint32_t*)c->img.p, (uint32_t)npix, (uint32_t)plan.tile_px, (uint32_t)g, (uint32_t)pad);
 	if (out_accum)
