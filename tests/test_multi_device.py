@@ -117,6 +117,20 @@ def test_multi_device_full_frame_and_rccl_communicator(hip):
 
 
 @pytest.mark.gpu
+def test_device_list_from_the_environment():
+    """sphip_create_multi(NULL): SPATH_HIP_DEVICES picks the devices (what hip_renderer::get relies on); nonsense is a loud error."""
+    code = ("from spath_amd import capi\n"
+            "c = capi.Context.multi()\n"
+            "print('devices', c.device_count, c.description)\n")
+    for env_val, want in (("0,0,0", "devices 3"), ("0", "devices 1")):
+        p = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SPATH_HIP_DEVICES=env_val), cwd=ROOT)
+        assert want in p.stdout, p.stdout + p.stderr[-1500:]
+    for bad in ("0;1", "zero", "0,,x", "99"):
+        p = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SPATH_HIP_DEVICES=bad), cwd=ROOT)
+        assert p.returncode != 0 and "sphip_create_multi" in p.stderr, (bad, p.stdout, p.stderr[-500:])
+
+
+@pytest.mark.gpu
 def test_cli_on_several_shards(tmp_path, O):
     """spath_cli --devices 0,0,0: the C++ adapter (hip_renderer::get_on) over a multi-device context."""
     t, m = scene.default_scene()
