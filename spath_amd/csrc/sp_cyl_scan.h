@@ -23,9 +23,10 @@
 // branch per 8 pairs, taken 70 % of the time, with eight compare-and-push blocks behind it, and an LDS queue per lane.
 // Here each lane folds the four x = |gm| - H*D of a group into their minimum, subtracts the margin and shifts the SIGN
 // BIT of the difference into a 32-bit word (v_min3_f32, v_min_f32, v_sub_f32, v_alignbit_b32: one instruction per pair,
-// no branch, no VCC, no LDS).  At the end of a 256-triangle tile every lane walks its set bits: re-reads the group's
-// four records (per-lane LDS addresses), recomputes the four x, and runs ray_tri_strict on each survivor.  There is no
-// queue, hence no overflow: a scene of huge triangles degrades smoothly to the exact-only scan.
+// no branch, no VCC).  At the end of a tile the set bits are resolved (stage 2): the group's four records are re-read, the four x
+// recomputed, ray_tri_strict run on each survivor -- by the lane that owns the ray (scan_cyl: 1-2 rays per lane), or by whichever
+// lane of the wave is free (scan_cylw further down: 4 rays per lane, the default).  There is no queue, hence no overflow: a scene
+// of huge triangles degrades smoothly to the exact-only scan.
 //
 // record: 32 B = 2 x float4 (class a, with (a,b,c) a cyclic rotation of (x,y,z)); tiles are stored chunk-major (cyl_slot):
 //   q0 = w_b/w_a  w_c/w_a  Mc.x/w_a  Mc.y/w_a        q1 = Mc.z/w_a  H/|w_a|  bits(original index)  0
@@ -39,10 +40,11 @@ namespace sp {
 #ifndef SP_CYL_TILE
 #define SP_CYL_TILE 384
 #endif
-// Triangles per LDS tile.  Stage 2 runs once per tile and lasts as long as the lane with the most set bits needs; the maximum
-// over 64 lanes of a Poisson count grows more slowly than its mean, so larger tiles mean fewer stage-2 rounds per triangle
-// (measured, 4 rays per lane: 12.85 rounds per 256 triangles with 256-triangle tiles).  384 x 32 B, double-buffered, plus
-// the bit words (12 KB at 4 rays per lane) is what four workgroups per CU can afford (36 KB each).
+// Triangles per LDS tile.  Stage 2 runs once per tile; with the per-lane form it lasts as long as the lane with the most set bits
+// needs, and the maximum over 64 lanes of a count grows more slowly than its mean, so larger tiles mean fewer stage-2 rounds per
+// triangle (measured, 4 rays per lane: 12.85 rounds per 256 triangles with 256-triangle tiles, 12.09 with 384); the wave-shared
+// form fills its 64-entry rounds better with more entries per slot.  384 x 32 B, double-buffered, plus the bit words of scan_cyl
+// (12 KB at 4 rays per lane) or the lists and best-hit cells of scan_cylw (14 KB) is what four workgroups per CU can afford.
 constexpr uint32_t kCylTile = SP_CYL_TILE;
 static_assert(kCylTile % 128 == 0, "whole waves per LDS-DMA pass, whole words of group bits");
 constexpr uint32_t kCylTileQ = 2u * kCylTile;     // float4 per tile
