@@ -117,6 +117,33 @@ def test_multi_device_full_frame_and_rccl_communicator(hip):
 
 
 @pytest.mark.gpu
+def test_all_visible_devices_when_there_are_several(hip):
+    """On a node with >= 2 GPUs: one context over all of them (distinct devices: the RCCL exchange, or peer copies if RCCL does not
+    come up) must reproduce device 0's image bit for bit.  A one-GPU box skips this; the several-shards-on-one-GPU tests above cover
+    everything but the cross-device transfers themselves."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU on this box")
+    t, m = scene.closed_room(2000)
+    hip.set_scene(t, m)
+    mc = capi.Context.multi(list(range(n)))
+    assert mc.device_count == n
+    mc.set_scene(t, m)
+    for (w, h, spp) in [(320, 180, 4), (97, 61, 5)]:
+        cam = view.Camera(w, h)
+        rays = cam.get_viewport()
+        want_img, want_acc = hip.render(rays, w, h, spp, seed=3, want_accum=True)
+        img, acc = mc.render(rays, w, h, spp, seed=3, want_accum=True)
+        st = mc.stats()
+        assert np.array_equal(img, want_img) and np.array_equal(acc, want_acc)
+        assert st["gather_kind"] in (capi.GATHER_RCCL, capi.GATHER_PEER) and st["scans_executed"] == hip.stats()["scans_executed"]
+        img2, acc2 = mc.render_camera(cam, spp, seed=3, want_accum=True)
+        assert np.array_equal(img2, want_img) and np.array_equal(acc2, want_acc)
+    mc.close()
+
+
+@pytest.mark.gpu
 def test_device_list_from_the_environment():
     """sphip_create_multi(NULL): SPATH_HIP_DEVICES picks the devices (what hip_renderer::get relies on); nonsense is a loud error."""
     code = ("from spath_amd import capi\n"
