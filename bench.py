@@ -366,6 +366,12 @@ def main():
         tr = profile_entry("hbm_traffic.json", key) or {}
         traffic = tr.get("hbm_bytes_per_launch")
         vi = profile_entry("valu_issue.json", key) or {}
+        if not vi and world > 1:
+            # instructions per ray-triangle test are a property of the kernel and the scene, not of the GPU count: rank 0's shard of
+            # an N-GPU run executes the same kernel on the same scene as the committed 1-GPU PMC pass
+            vi = dict(profile_entry("valu_issue.json", f"{NT}tris_{W}x{H}x{SPP}_g1_{kname}") or {})
+            if vi:
+                vi["source"] = vi.get("source", "") + " [1-GPU pass of the same kernel and scene, applied to rank 0's shard]"
         fs = profile_entry("filter_stats.json", f"{NT}tris_{W}x{H}_{kname}") or {}
         tests_per_s = my_scans * NT / avg_kernel_s
         lane_instr = vi.get("lane_instr_per_test")
