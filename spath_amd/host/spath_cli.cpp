@@ -6,9 +6,12 @@
 //   spath_cli [--scene default|FILE.bin] [--w 640 --h 480] [--spp 128] [--mode pt|flat]
 //             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--out image.ppm|image.rgba] [--frames n]
 //             [--device-viewport] [--gpus n | --devices 0,1,...]
+// --out: .ppm (binary P6), .png (8-bit RGB, stored deflate blocks: no compression library needed), anything else = raw RGBA8
 #include "hip_renderer.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +48,60 @@ void default_scene(std::vector<geom::triangle>& t, std::vector<scene::material>&
 		const float e = (i == 3 || i == 4) ? 1.0f : 0.0f;
 		m[i].emittance_color = geom::vec3(e, e, e);
 	}
+}
+
+// ---- minimal PNG writer: 8-bit RGB, filter 0 on every row, zlib stream of STORED deflate blocks (RFC 1950/1951/2083)
+uint32_t crc32_of(const unsigned char* p, size_t n, uint32_t crc = 0) {
+	static uint32_t tab[256];
+	static bool init = false;
+	if (!init) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; tab[i] = c; } init = true; }
+	crc = ~crc;
+	for (size_t i = 0; i < n; ++i) crc = tab[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+	return ~crc;
+}
+
+void png_chunk(FILE* o, const char* type, const std::vector<unsigned char>& data) {
+	unsigned char len[4] = { (unsigned char)(data.size() >> 24), (unsigned char)(data.size() >> 16), (unsigned char)(data.size() >> 8), (unsigned char)data.size() };
+	std::fwrite(len, 1, 4, o);
+	std::vector<unsigned char> td(type, type + 4);
+	td.insert(td.end(), data.begin(), data.end());
+	std::fwrite(td.data(), 1, td.size(), o);
+	const uint32_t c = crc32_of(td.data(), td.size());
+	unsigned char cb[4] = { (unsigned char)(c >> 24), (unsigned char)(c >> 16), (unsigned char)(c >> 8), (unsigned char)c };
+	std::fwrite(cb, 1, 4, o);
+}
+
+void write_png(FILE* o, const scene::bitmap& bmp) {
+	const size_t w = bmp.res_x, h = bmp.res_y;
+	std::vector<unsigned char> raw;                       // filter byte + RGB per row (row 0 = top, as stored)
+	raw.reserve(h * (1 + 3 * w));
+	for (size_t j = 0; j < h; ++j) {
+		raw.push_back(0);
+		for (size_t i = 0; i < w; ++i) { const scene::RGBA& p = bmp.values[j * w + i]; raw.push_back(p.r); raw.push_back(p.g); raw.push_back(p.b); }
+	}
+	std::vector<unsigned char> z;
+	z.push_back(0x78); z.push_back(0x01);                 // zlib header, no compression
+	uint32_t a = 1, b = 0;                                // Adler-32 of the raw data
+	for (size_t i = 0; i < raw.size(); ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+	for (size_t pos = 0; pos < raw.size() || pos == 0; ) {
+		const size_t n = std::min<size_t>(65535, raw.size() - pos);
+		const bool last = pos + n >= raw.size();
+		z.push_back(last ? 1 : 0);
+		z.push_back((unsigned char)(n & 0xff)); z.push_back((unsigned char)(n >> 8));
+		z.push_back((unsigned char)(~n & 0xff)); z.push_back((unsigned char)((~n >> 8) & 0xff));
+		z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+		pos += n;
+		if (last) break;
+	}
+	const uint32_t ad = (b << 16) | a;
+	z.push_back((unsigned char)(ad >> 24)); z.push_back((unsigned char)(ad >> 16)); z.push_back((unsigned char)(ad >> 8)); z.push_back((unsigned char)ad);
+	static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+	std::fwrite(sig, 1, 8, o);
+	std::vector<unsigned char> hd = { (unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w,
+	                                  (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h, 8, 2, 0, 0, 0 };
+	png_chunk(o, "IHDR", hd);
+	png_chunk(o, "IDAT", z);
+	png_chunk(o, "IEND", std::vector<unsigned char>());
 }
 
 bool load_scene(const char* path, std::vector<geom::triangle>& t, std::vector<scene::material>& m) {   // 'SPSC' file of spath_amd/scene.py
@@ -128,6 +185,8 @@ int main(int argc, char** argv) {
 			if (out_path.size() > 4 && out_path.substr(out_path.size() - 4) == ".ppm") {
 				std::fprintf(o, "P6\n%zu %zu\n255\n", bmp.res_x, bmp.res_y);
 				for (size_t i = 0; i < bmp.values.size(); ++i) std::fwrite(&bmp.values[i], 1, 3, o);   // row 0 = top, as stored
+			} else if (out_path.size() > 4 && out_path.substr(out_path.size() - 4) == ".png") {
+				write_png(o, bmp);
 			} else {
 				std::fwrite(bmp.values.data(), sizeof(scene::RGBA), bmp.values.size(), o);
 			}

@@ -58,6 +58,23 @@ def test_cli_images_equal_oracle(tmp_path, O):
     assert raw.startswith(b"P6\n40 30\n255\n")
     want = O.render_counter(O.viewport(40, 30), ts, ms, 2, 1)[0][:, :3]
     assert np.array_equal(np.frombuffer(raw[len(b"P6\n40 30\n255\n"):], dtype=np.uint8).reshape(-1, 3), want)
+    # PNG output (stored deflate blocks), decoded here with zlib: signature, IHDR, CRCs, filter-0 rows
+    import struct, zlib
+    png = os.path.join(tmp_path, "a.png")
+    subprocess.run([CLI, "--scene", sp, "--w", "40", "--h", "30", "--spp", "2", "--out", png], check=True, capture_output=True)
+    raw = open(png, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(typ + data) & 0xffffffff)
+        chunks.setdefault(typ, b"")
+        chunks[typ] += data
+        pos += 12 + n
+    assert struct.unpack(">IIBBBBB", chunks[b"IHDR"]) == (40, 30, 8, 2, 0, 0, 0) and b"IEND" in chunks
+    rows = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), dtype=np.uint8).reshape(30, 1 + 3 * 40)
+    assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(-1, 3), want)
 
 
 @pytest.mark.gpu
