@@ -29,6 +29,10 @@ struct KArgs {
 	// samp[(sample * 3 + c) * samp_stride + ray] and k_resolve adds them up in sample order.  n_chunks <= 1: off
 	uint32_t n_chunks, px_blocks, samp_stride;
 	float* samp;
+	// primary-hit reuse of the two-stage kernels (flags & 0x100): closest hit of every ray of the launch, from a pre-pass
+	// (k_hit_filter, one scan per PIXEL); k_pt_filter starts every sample of the pixel from it.  nullptr: off
+	const int*   prim_idx;     // n_rays
+	const float* prim_d;       // n_rays
 };
 
 // second pass of a sample-chunked launch: cpu_renderer.cpp:72-78 for one pixel -- zero, += sample in sample order,

@@ -105,25 +105,17 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 #pragma unroll
 		for (int c = 0; c < 3; ++c) acc[(size_t)c * n_work + k0 + r * 256u] = 0.0f;
 	}
-	const bool reuse = (a.flags & 0x100u) != 0;
+	// primary-hit reuse: cpu_renderer.cpp:74-76 starts every sample from the same vp.rays[idx], so the first
+	// scan of all samples of a pixel has one result; the host ran it once per pixel (k_hit_filter) before this launch
+	const bool reuse = a.prim_idx != nullptr;
 	uint32_t my_scans = 0;
 	float pd[R]; int pi[R];
-	if (reuse) {
-		RaySlots<R> s;
 #pragma unroll
-		for (int r = 0; r < R; ++r) {
-			const uint32_t k = kr0 + r * kstep;
-			const bool valid = k < a.n_rays;
-			const float* pr = a.rays + (size_t)(valid ? k : a.n_rays - 1) * 6;
-			s.o[r] = mk3(pr[0], pr[1], pr[2]); s.dir[r] = mk3(pr[3], pr[4], pr[5]);
-			s.src[r] = -1; s.act[r] = valid && (!SPLIT || r == 0);
-			my_scans += s.act[r] ? 1u : 0u;
-		}
-		two_stage_scan<R, SCAN>(a, src2, rv, s, pd, pi);
-		if (SPLIT) {
-#pragma unroll
-			for (int r = 1; r < R; ++r) { pd[r] = pd[0]; pi[r] = pi[0]; }
-		}
+	for (int r = 0; r < R; ++r) {
+		const uint32_t k = kr0 + r * kstep;
+		const uint32_t kk = k < a.n_rays ? k : a.n_rays - 1;
+		pd[r] = reuse ? a.prim_d[kk] : 0.0f;
+		pi[r] = reuse ? a.prim_idx[kk] : -1;
 	}
 
 	const uint32_t n_iter = SPLIT ? (a.n_samples + R - 1) / R : a.n_samples;

@@ -40,7 +40,7 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, bvh_sort, bvh_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, bvh_sort, bvh_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim;
 	bool bvh_valid = false;
 	uint32_t bvh_leaves = 0;
 	size_t n_tris = 0;
@@ -293,6 +293,23 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		B.n_leaves = c->bvh_leaves; B.first_leaf = c->bvh_leaves; B.meta = (const uint32_t*)c->bvh_meta.p;
 	}
 	HIP_TRY(c, hipEventRecord(c->ev_k0, st));
+	// primary-hit reuse with a two-stage kernel: one closest-hit scan per PIXEL first (R pixels per lane, the same scan family),
+	// whatever the number of samples and sample chunks; the path-tracing launch then starts every sample from that hit
+	bool prim_pass = false;
+	if (mode == SPHIP_MODE_PT && is_ts && (flags & SPHIP_FLAG_PRIMARY_REUSE)) {
+		if ((rc = ensure(c, c->prim, n_rays * 8))) return rc;
+		int* oi = (int*)c->prim.p; float* od = (float*)((char*)c->prim.p + n_rays * 4);
+		sp::KArgs h = a;
+		h.n_chunks = 0; h.samp = nullptr;
+		const int* no_src = nullptr;
+#define SP_PRIM(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, h, src2, bnd, no_src, oi, od)
+		if (ts.scan == 0) { if (ts.R == 4) SP_PRIM(4, 0); else if (ts.R == 2) SP_PRIM(2, 0); else SP_PRIM(1, 0); }
+		else if (ts.scan == 2) SP_PRIM(4, 2);
+		else              { if (ts.R == 4) SP_PRIM(4, 1); else if (ts.R == 2) SP_PRIM(2, 1); else SP_PRIM(1, 1); }
+#undef SP_PRIM
+		a.prim_idx = oi; a.prim_d = od;
+		prim_pass = true;
+	}
 	if (variant == kVariantAccel) {
 		if (mode == kModeHits)           hipLaunchKernelGGL(sp::k_accel<2>, grid, block, 0, st, a, B, d_src, (int*)d_rgba, (float*)d_accum);
 		else if (mode == SPHIP_MODE_FLAT) hipLaunchKernelGGL(sp::k_accel<0>, grid, block, 0, st, a, B, nullptr, nullptr, nullptr);
@@ -343,7 +360,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	c->stats.n_tris = c->n_tris;
 	c->stats.n_pixels = n_rays;
 	c->stats.kernel_variant = (uint32_t)variant;
-	c->stats.n_launches = chunks > 1 ? 2 : 1;
+	c->stats.n_launches = (chunks > 1 ? 2u : 1u) + (prim_pass ? 1u : 0u);
 	return SPHIP_OK;
 }
 
@@ -746,8 +763,8 @@ void sphip_destroy(sphip_t* c) {
 	}
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[20] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
-	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->bvh_sort, &c->bvh_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr };
+	DevBuf* bufs[21] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->bvh_sort, &c->bvh_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);

@@ -4,10 +4,11 @@
 // '+'/'-' -> --spp, 'p' -> --mode.  The image goes to a binary PPM or a raw RGBA file.
 //
 //   spath_cli [--scene default|FILE.bin] [--w 640 --h 480] [--spp 128] [--mode pt|flat]
-//             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--out image.ppm|image.rgba] [--frames n]
+//             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--primary-reuse] [--out image.ppm|image.rgba] [--frames n]
 //             [--device-viewport] [--gpus n | --devices 0,1,...]
 // --out: .ppm (binary P6), .png (8-bit RGB, stored deflate blocks: no compression library needed), anything else = raw RGBA8
 #include "hip_renderer.h"
+#include "spath_hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -138,6 +139,7 @@ int main(int argc, char** argv) {
 			else if (k == "--mode") { need(1); mode = argv[++i]; }
 			else if (k == "--seed") { need(1); seed = std::strtoull(argv[++i], 0, 0); }
 			else if (k == "--flags") { need(1); flags = std::atoi(argv[++i]); }
+			else if (k == "--primary-reuse") flags |= SPHIP_FLAG_PRIMARY_REUSE;   // one primary scan per pixel (identical image)
 			else if (k == "--frames") { need(1); frames = std::atoi(argv[++i]); }
 			else if (k == "--out") { need(1); out_path = argv[++i]; }
 			else if (k == "--device-viewport") device_viewport = true;

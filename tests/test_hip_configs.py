@@ -81,6 +81,11 @@ def test_configs2_real_launch_shape_256spp(hip, O):
     assert b_st["n_launches"] == 1
     assert np.array_equal(a_img, b_img) and np.array_equal(a_acc, b_acc) and a_st["scans_executed"] == b_st["scans_executed"]
     assert abs(a_st["scans_executed"] - w * h * spp * 5) <= 1e-5 * w * h * spp * 5
+    # SURVEY 8(f3), opt-in: the primary hit of each pixel from a one-scan-per-pixel pre-pass -- same bits, 1/5 fewer scans
+    c_img, c_acc, c_st = _render_shard(hip, d_rays, w * h, None, w, spp, seed, capi.FLAG_PRIMARY_REUSE)
+    assert c_st["n_launches"] == 3 and c_st["kernel_variant"] == 15
+    assert np.array_equal(a_img, c_img) and np.array_equal(a_acc, c_acc)
+    assert c_st["scans_executed"] == a_st["scans_executed"] - w * h * (spp - 1)
     p0, n = 540 * w + 700, 256
     want_img, want_acc, _ = O.render_counter(rays, t, m, spp, seed, pix0=p0, npix=n)
     assert np.array_equal(a_img[p0:p0 + n], want_img) and np.array_equal(a_acc[p0:p0 + n], want_acc)
