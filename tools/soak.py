@@ -64,7 +64,10 @@ while time.time() < t_end:
         img, acc = ctx.render(rays, w, h, spp, seed=seed, flags=var | chunks, want_accum=True); st = ctx.stats()
         flat = ctx.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=var)
         hi, hd = hits(var)
+        # opt-in primary-hit reuse (per-pixel closest-hit pre-pass): same bits, w*h*(spp-1) scans fewer
+        rimg, racc = ctx.render(rays, w, h, spp, seed=seed, flags=var | chunks | capi.FLAG_PRIMARY_REUSE, want_accum=True); rst = ctx.stats()
         ok = np.array_equal(img, want[0]) and np.array_equal(acc, want[1]) and st["scans_executed"] == ws and np.array_equal(flat, wflat) and np.array_equal(hi, whi) and np.array_equal(hd, whd)
+        ok = ok and np.array_equal(rimg, want[0]) and np.array_equal(racc, want[1]) and rst["scans_executed"] == ws - w * h * (spp - 1)
         if not ok:
             fails += 1
             print(f"MISMATCH it {it}: {names[var]} n={n} kind={kind} {w}x{h} spp={spp} seed={seed} chunks={chunks >> 16}: img {np.array_equal(img, want[0])} acc {np.array_equal(acc, want[1])} "
