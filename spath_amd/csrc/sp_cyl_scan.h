@@ -28,8 +28,12 @@
 // lane of the wave is free (scan_cylw further down: 4 rays per lane, the default).  There is no queue, hence no overflow: a scene
 // of huge triangles degrades smoothly to the exact-only scan.
 //
-// record: 32 B = 2 x float4 (class a, with (a,b,c) a cyclic rotation of (x,y,z)); tiles are stored chunk-major (cyl_slot):
-//   q0 = w_b/w_a  w_c/w_a  Mc.x/w_a  Mc.y/w_a        q1 = Mc.z/w_a  H/|w_a|  bits(original index)  0
+// record: 6 floats + the index (class a, with (a,b,c) a cyclic rotation of (x,y,z)):
+//   q0 = w_b/w_a  w_c/w_a  Mc.x/w_a  Mc.y/w_a        (Mc.z/w_a, H/|w_a|)        bits(original index)
+// A GROUP of four triangles is eight float4 "chunks" (128 B): chunks 0-3 = q0 of triangles 0-3, chunk 4 = (Mz0 H0 Mz1 H1),
+// chunk 5 = (Mz2 H2 Mz3 H3), chunk 6 = the four indices, chunk 7 unused -- stage 1 reads six 16-B chunks per group (six
+// ds_read_b128, 4 LDS cycles each; with a (q0, q1) pair per triangle it needed the .xy of four q1: two ds_read2st64_b64 at
+// 8 cycles each).  Tiles are stored chunk-major (cyl_slot).
 #pragma once
 
 #include "sp_kernels.h"
@@ -60,6 +64,30 @@ struct CylStream {
 	const float4* rec;       // class-major stream; every class starts on a tile boundary
 	const uint32_t* hdr;     // [0..2] triangles per class, [3..5] first tile of each class (k_cyl_offsets)
 };
+
+// triangle u of group grp of a tile: q0 -> chunk u; (q1.x, q1.y) = (Mz, H) -> chunk 4 + u/2, half u%2; q1.z = index bits -> chunk 6, lane u
+SP_DEV void cyl_store(float4* __restrict__ tile, uint32_t grp, uint32_t u, const float4 q0, const float4 q1) {
+	tile[cyl_slot(grp, u)] = q0;
+	float* mh = (float*)(tile + cyl_slot(grp, 4u + (u >> 1))) + 2u * (u & 1u);
+	mh[0] = q1.x; mh[1] = q1.y;
+	((float*)(tile + cyl_slot(grp, 6u)))[u] = q1.z;
+	if (u == 0u) tile[cyl_slot(grp, 7u)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// the stage-1 data of a group: six float4
+struct CylGroup {
+	float4 q0[4];
+	float4 mh01, mh23;      // (Mz, H) of triangles 0,1 and 2,3
+};
+SP_DEV CylGroup cyl_group(const float4* tile, uint32_t grp) {
+	CylGroup G;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) G.q0[u] = tile[cyl_slot(grp, (uint32_t)u)];
+	G.mh01 = tile[cyl_slot(grp, 4u)]; G.mh23 = tile[cyl_slot(grp, 5u)];
+	return G;
+}
+SP_DEV float cyl_mz(const CylGroup& G, int u) { return u == 0 ? G.mh01.x : u == 1 ? G.mh01.z : u == 2 ? G.mh23.x : G.mh23.z; }
+SP_DEV float cyl_h(const CylGroup& G, int u) { return u == 0 ? G.mh01.y : u == 1 ? G.mh01.w : u == 2 ? G.mh23.y : G.mh23.w; }
 
 // ---- record of one triangle (double arithmetic, each coefficient rounded once).  Returns the class.
 SP_DEV int cyl_record(const float* __restrict__ t, uint32_t idx, float4& q0, float4& q1) {
@@ -166,8 +194,7 @@ __global__ void __launch_bounds__(256) k_cyl_scatter(const float* __restrict__ t
 		const size_t pos = (size_t)hdr[3 + cls] * kCylTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
 		const size_t tile = pos / kCylTile;
 		const uint32_t in_tile = (uint32_t)(pos - tile * kCylTile), grp = in_tile >> 2, u = in_tile & 3u;
-		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u)] = q0;
-		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u + 1u)] = q1;
+		cyl_store(rec + tile * kCylTileQ, grp, u, q0, q1);
 	}
 }
 
@@ -180,8 +207,7 @@ __global__ void __launch_bounds__(256) k_cyl_pad(const uint32_t* __restrict__ hd
 	for (uint32_t pos = n + tid; pos < (n + kCylTile - 1u) / kCylTile * kCylTile; pos += 256u) {
 		const size_t gpos = (size_t)first + pos, tile = gpos / kCylTile;
 		const uint32_t in_tile = (uint32_t)(gpos - tile * kCylTile), grp = in_tile >> 2, u = in_tile & 3u;
-		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		rec[tile * kCylTileQ + cyl_slot(grp, 2u * u + 1u)] = make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f);
+		cyl_store(rec + tile * kCylTileQ, grp, u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f));
 	}
 }
 
@@ -196,13 +222,13 @@ SP_DEV void cyl_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t t
 }
 
 // x = |gm| - H*D for one (record, ray): 6 VALU
-SP_DEV float cyl_x(const float4 q0, const float4 q1, float Pa, float Pb, float Pc, float ndx, float ndy, float ndz, float D) {
+SP_DEV float cyl_x(const float4 q0, float mz, float H, float Pa, float Pb, float Pc, float ndx, float ndy, float ndz, float D) {
 	float gm = __builtin_fmaf(q0.x, Pb, Pa);
 	gm = __builtin_fmaf(q0.y, Pc, gm);
 	gm = __builtin_fmaf(ndx, q0.z, gm);
 	gm = __builtin_fmaf(ndy, q0.w, gm);
-	gm = __builtin_fmaf(ndz, q1.x, gm);
-	return __builtin_fmaf(-q1.y, D, __builtin_fabsf(gm));
+	gm = __builtin_fmaf(ndz, mz, gm);
+	return __builtin_fmaf(-H, D, __builtin_fabsf(gm));
 }
 
 template <int R>
@@ -270,7 +296,7 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 		}
 		const float4* cur = sm + (gt & 1u) * kCylTileQ;
 		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kCylTile;
-		const uint32_t ngroups = ((left < kCylTile ? left : kCylTile) + 3u) / 4u;
+		const uint32_t ngroups = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kCylTile ? left : kCylTile) + 3u) / 4u));   // a scalar loop bound
 		// ---- stage 1: one bit per (group, slot); the first group ends up in the most significant bits
 		uint32_t nz = 0;                                  // bit wi: this lane's word wi has a bit set
 		uint32_t g = 0;
@@ -280,14 +306,12 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 			const uint32_t gend = ngroups < (uint32_t)(wi + 1) * kGPW ? ngroups : (uint32_t)(wi + 1) * kGPW;
 			const uint32_t g0 = g;
 			for (; g < gend; ++g) {
-				float4 a0[4], a1[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) { a0[u] = cur[cyl_slot(g, 2 * u)]; a1[u] = cur[cyl_slot(g, 2 * u + 1)]; }
+				const CylGroup G = cyl_group(cur, g);
 #pragma unroll
 				for (int r = 0; r < R; ++r) {
 					float x[4];
 #pragma unroll
-					for (int u = 0; u < 4; ++u) x[u] = cyl_x(a0[u], a1[u], f.Pa[r], f.Pb[r], f.Pc[r], f.ndx[r], f.ndy[r], f.ndz[r], f.D[r]);
+					for (int u = 0; u < 4; ++u) x[u] = cyl_x(G.q0[u], cyl_mz(G, u), cyl_h(G, u), f.Pa[r], f.Pb[r], f.Pc[r], f.ndx[r], f.ndy[r], f.ndz[r], f.D[r]);
 					const float m = __builtin_fminf(__builtin_fminf(x[0], x[1]), __builtin_fminf(x[2], x[3]));
 					wv = __builtin_amdgcn_alignbit(wv, __float_as_uint(m - f.Dq[r]), 31);      // (wv << 1) | sign(m - Dq)
 				}
@@ -341,13 +365,14 @@ SP_DEV void scan_cyl(const KArgs& a, const CylStream cs, float rv, const RaySlot
 				}
 				// the group's four records (per-lane LDS address) and their x again; the first survivor not yet done
 				uint32_t cand = 0; int idx = 0;
+				const CylGroup G = cyl_group(cur, grp);
+				const float4 gi = cur[cyl_slot(grp, 6u)];
 #pragma unroll
 				for (int u = 3; u >= 0; --u) {
-					const float4 q0 = cur[cyl_slot(grp, 2 * u)], q1 = cur[cyl_slot(grp, 2 * u + 1)];
-					const float x = cyl_x(q0, q1, Pa, Pb, Pc, ndx, ndy, ndz, D);
+					const float x = cyl_x(G.q0[u], cyl_mz(G, u), cyl_h(G, u), Pa, Pb, Pc, ndx, ndy, ndz, D);
 					const bool sv = !(x - Dq >= 0.0f) && !((sub >> u) & 1u);      // the sign-bit decision again; NaN -> survivor
 					cand = sv ? (cand | (1u << u)) : cand;
-					idx = sv ? (int)__float_as_uint(q1.z) : idx;               // ends as the lowest surviving u's index
+					idx = sv ? (int)__float_as_uint(u == 0 ? gi.x : u == 1 ? gi.y : u == 2 ? gi.z : gi.w) : idx;   // ends as the lowest surviving u's index
 				}
 				const uint32_t lowest = cand & (0u - cand);
 				const bool last = (cand == lowest);                             // no further survivor in this group
@@ -432,7 +457,7 @@ SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		}
 		const float4* cur = sm + (gt & 1u) * kCylTileQ;
 		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kCylTile;
-		const uint32_t ngroups = ((left < kCylTile ? left : kCylTile) + 3u) / 4u;
+		const uint32_t ngroups = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kCylTile ? left : kCylTile) + 3u) / 4u));   // a scalar loop bound
 		// ---- stage 1: word[r][wi] bit (31 - k) = group 32*wi + k of this tile survives for ray r
 		uint32_t word[R][kW];
 		uint32_t g = 0;
@@ -444,14 +469,12 @@ SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			const uint32_t gend = ngroups < (uint32_t)(wi + 1) * 32u ? ngroups : (uint32_t)(wi + 1) * 32u;
 			const uint32_t g0 = g;
 			for (; g < gend; ++g) {
-				float4 a0[4], a1[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) { a0[u] = cur[cyl_slot(g, 2 * u)]; a1[u] = cur[cyl_slot(g, 2 * u + 1)]; }
+				const CylGroup G = cyl_group(cur, g);
 #pragma unroll
 				for (int r = 0; r < R; ++r) {
 					float x[4];
 #pragma unroll
-					for (int u = 0; u < 4; ++u) x[u] = cyl_x(a0[u], a1[u], f.Pa[r], f.Pb[r], f.Pc[r], f.ndx[r], f.ndy[r], f.ndz[r], f.D[r]);
+					for (int u = 0; u < 4; ++u) x[u] = cyl_x(G.q0[u], cyl_mz(G, u), cyl_h(G, u), f.Pa[r], f.Pb[r], f.Pc[r], f.ndx[r], f.ndy[r], f.ndz[r], f.D[r]);
 					const float m = __builtin_fminf(__builtin_fminf(x[0], x[1]), __builtin_fminf(x[2], x[3]));
 					wv[r] = __builtin_amdgcn_alignbit(wv[r], __float_as_uint(m - f.Dq[r]), 31);      // (wv << 1) | sign(m - Dq)
 				}
@@ -507,15 +530,19 @@ SP_DEV void scan_cylw(const KArgs& a, const CylStream cs, float rv, const RaySlo
 					// (a ray whose filter is off has a zero moment and Dq = +inf: it survives whatever x comes out, so -dir serves for all)
 					// the group's four records and their x again: which of the four survive
 					uint32_t cand = 0;
-					int idx4[4];
+					const CylGroup G = cyl_group(cur, grp);
+					const float4 gi = cur[cyl_slot(grp, 6u)];
+					const int idx4[4] = { (int)__float_as_uint(gi.x), (int)__float_as_uint(gi.y), (int)__float_as_uint(gi.z), (int)__float_as_uint(gi.w) };
 #pragma unroll
 					for (int u = 0; u < 4; ++u) {
-						const float4 q0 = cur[cyl_slot(grp, 2 * u)], q1 = cur[cyl_slot(grp, 2 * u + 1)];
-						const float x = cyl_x(q0, q1, Pa, Pb, Pc, -dx, -dy, -dz, D);
+						const float x = cyl_x(G.q0[u], cyl_mz(G, u), cyl_h(G, u), Pa, Pb, Pc, -dx, -dy, -dz, D);
 						cand |= (ok && !(x - Dq >= 0.0f)) ? (1u << u) : 0u;          // the sign-bit decision again; NaN -> survivor
-						idx4[u] = (int)__float_as_uint(q1.z);
 					}
-					while (__any(cand != 0u)) {                               // one exact test per lane and turn (1.09 per entry on average)
+					// one exact test per lane and turn: 1.09 per entry on average, 1.57 wave-wide turns per round (some lane has two or three)
+					while (__any(cand != 0u)) {
+#ifdef SP_FILTER_STATS
+						if (lane == 0) atomicAdd(a.scans + 5, 1ull);
+#endif
 						if (cand != 0u) {
 							const uint32_t low = cand & (0u - cand);
 							cand ^= low;

@@ -22,7 +22,7 @@ SP_DEV void two_stage_scan(const KArgs& a, const ScanSrc& src, float rv, const R
 
 // ---- the closest-hit scan alone with a two-stage scan; R rays per lane
 template <int R, int SCAN>
-__global__ void __launch_bounds__(256) k_hit_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds,
+__global__ void __launch_bounds__(256, SP_PT_WAVES) k_hit_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds,
                                                     const int* __restrict__ src_idx, int* __restrict__ out_idx, float* __restrict__ out_d) {
 	const float rv = __uint_as_float(bounds[0]);
 	RaySlots<R> s;
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_hit_filter(const KArgs a, const ScanSrc
 
 // ---- renderer::render_flat with a two-stage scan; R pixels per lane
 template <int R, int SCAN>
-__global__ void __launch_bounds__(256) k_flat_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds) {
+__global__ void __launch_bounds__(256, SP_PT_WAVES) k_flat_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds) {
 	const float rv = __uint_as_float(bounds[0]);
 	const uint32_t tid = threadIdx.x;
 	RaySlots<R> s;

@@ -924,11 +924,12 @@ int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 #endif
 #ifdef SP_FILTER_STATS
 	{
-		unsigned long long x[5] = {0, 0, 0, 0, 0};
+		unsigned long long x[6] = {0, 0, 0, 0, 0, 0};
 		(void)hipMemcpy(x, c->counter.p, sizeof x, hipMemcpyDeviceToHost);
 		if (c->stats.kernel_variant >= 9)
-			fprintf(stderr, "[cyl stats] group bits set=%llu stage-2 rounds(per wave)=%llu wave-tiles=%llu exact tests=%llu -> bits/lane/tile=%.3f rounds/tile=%.2f exact per bit=%.3f lane utilisation in stage 2=%.3f\n",
-			        x[1], x[2], x[3], x[4], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3], (double)x[4] / (double)x[1], (double)x[4] / (64.0 * (double)x[2]));
+			fprintf(stderr, "[cyl stats] group bits set=%llu stage-2 rounds(per wave)=%llu wave-tiles=%llu exact tests=%llu -> bits/lane/tile=%.3f rounds/tile=%.2f exact per bit=%.3f lane utilisation in stage 2=%.3f wave-wide exact turns=%llu (%.2f per round, %.3f of their lanes used)\n",
+			        x[1], x[2], x[3], x[4], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3], (double)x[4] / (double)x[1], (double)x[4] / (64.0 * (double)x[2]),
+			        x[5], (double)x[5] / (double)x[2], (double)x[4] / (64.0 * (double)x[5]));
 		else
 		fprintf(stderr, "[filter stats] survivors=%llu rounds(sum of per-wave max)=%llu wave_flushes=%llu overflows=%llu -> survivors/lane/flush=%.3f rounds/flush=%.2f\n",
 		        x[1], x[2], x[3], x[4], (double)x[1] / (64.0 * (double)x[3]), (double)x[2] / (double)x[3]);
