@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_cyl_count(const float* __restrict__ tri
 
 // ---- pass 2 (one workgroup): exclusive prefix of the block counts per class; hdr[0..2] = class sizes,
 // hdr[3..5] = first tile of each class, hdr[6] = tiles in total
-__global__ void __launch_bounds__(256) k_cyl_offsets(uint32_t* __restrict__ block_counts, uint32_t nblocks, uint32_t* __restrict__ hdr) {
+__global__ void __launch_bounds__(256) k_cyl_offsets(uint32_t* __restrict__ block_counts, uint32_t nblocks, uint32_t* __restrict__ hdr, uint32_t tile_sz) {
 	__shared__ uint32_t part[256];
 	__shared__ uint32_t total[3];
 	const uint32_t tid = threadIdx.x;
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) k_cyl_offsets(uint32_t* __restrict__ bloc
 	}
 	if (tid == 0) {
 		uint32_t tile = 0;
-		for (int k = 0; k < 3; ++k) { hdr[k] = total[k]; hdr[3 + k] = tile; tile += (total[k] + kCylTile - 1u) / kCylTile; }
+		for (int k = 0; k < 3; ++k) { hdr[k] = total[k]; hdr[3 + k] = tile; tile += (total[k] + tile_sz - 1u) / tile_sz; }
 		hdr[6] = tile;
 	}
 }

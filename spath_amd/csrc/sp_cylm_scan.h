@@ -1,0 +1,325 @@
+// Third generation of the closest-hit scan: the cylinder test of sp_cyl_scan.h with its side product on the FP16 MATRIX pipe.
+// Same closest hit, same ties as cpu_renderer.cpp:36-49 (stage 2 is scan_cylw's: exact test of every survivor, best (d, index)).
+//
+// Stage 1 of sp_cyl_scan.h spends 5 of its 7 VALU instructions per (ray, triangle) on gm = P_a + b P_b + c P_c - dir.Mc'
+//  -- a bilinear form of a 5-vector of the ray and a 5-vector of the triangle, i.e. a matrix product over all
+// pairs.  The f32 matrix instructions run at the VALU's rate; the f16 ones at 16x.  gm needs ~2^-19 relative accuracy
+// (the margin Dq is 2^-16 of the magnitudes involved), which one half-precision product does not give, but three do:
+//     v = hi + lo  (hi = half(v), lo = half(v - hi);  |v - hi - lo| <= 2^-22 |v|)
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi       (each product of two halves is exact in the f32 accumulator)
+// The five products take 15 of the K = 16 slots of ONE v_mfma_f32_32x32x16_f16 and P_a (coefficient 1) the sixteenth -- as a
+// single half: the test is invariant under scaling the ray, so the ray is scaled by t = half(P_a)/P_a (|t - 1| <= 2^-11), which
+// makes its P_a exactly a half (when P_a is too small for that, t = 1 and the dropped part, < 2^-22, is added to the margin).
+// One instruction = 32 triangles (A rows) x 32 rays (B columns) = 1024 side products in 32 cycles of the matrix
+// pipe; the VALU is left with x = fma(-H, D, |gm|), the min over a group of four triangles and the sign bit: 2 instructions per pair
+// (tools/mfma16_stage1_bench.hip: 18.1 T pairs/s against 7.5 for the VALU form on the same data).
+//
+// Scaling.  Halves hold 6e-5 .. 65504, so both sides are scaled by EXACT powers of two: S = 2^k in [2Rv, 4Rv) for lengths
+// (Rv = the scene bound of sp_filter_scan.h), s_d = 2^-e for the ray direction (largest |dir| component in [1, 2) afterwards):
+//     triangle side:  16 b, 16 c, 16 Mc'/S          (|.| <= 16 and <= 14)         H^ = 256 H / S
+//     ray side:       16 s_d P/S, 16 s_d (-dir)     (|.| <= 2^15 and <= 32)       D^ = s_d D,  Dq^ = 256 s_d Dq / S      (all times t)
+// so that every term of gm^ is 256 s_d / S times the term of gm: the test |gm^| - H^ D^ > Dq^ is the test |gm| - H D > Dq.  A ray
+// further than 512 S from the origin, or outside the guards of cyl_setup, has its filter off (everything survives) as before.
+//
+// Error budget (u = 2^-24, X = |dir|(|pos| + 2Rv) sqrt(3) bounding the sum of the |terms| as in DESIGN.md 4.2): splitting
+// 3 x 2^-22 = 12u per product, the accumulation of 16 terms in f32 <= 16u, the scaling by t 2u, against the 7u of the VALU chain
+// they replace; needed by the proof 152u + (30u - 7u) sqrt(3) = 192u of the 256u the margin provides.
+// Absolute floors (subnormal lo parts, 2^-25 per value) are 2^-13 of that after the scaling by 16.
+//
+// Work shape: ONE ray per lane (the matrix instruction reads a whole 32-triangle fragment with one 16-B LDS read per lane, so
+// nothing is gained from several rays per lane).  A wave owns 64 rays = two column blocks; lane l holds, of ray block rb, column
+// l & 31 -- its own ray when (l >> 5) == rb, its partner's otherwise -- and the rows (triangles) 8j + 4(l >> 5) + i of a
+// fragment: the four i of a j are one GROUP of sp_cyl_scan.h, so the sign bits are per (ray, group) exactly as there.
+// Tile: 192 triangles = 12 KB: [8 chunks][48 groups] float4 as in sp_cyl_scan.h (chunk 7 = the four H^ of the group) followed by
+// the A fragments [6 blocks of 32][64 lanes] x 16 B.
+#pragma once
+
+#include "sp_cyl_scan.h"
+
+namespace sp {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t kMTile = 192u;                 // triangles per tile
+constexpr uint32_t kMGroups = kMTile / 4u;        // 48
+constexpr uint32_t kMBlocks = kMTile / 32u;       // 6 fragments
+constexpr uint32_t kMRecQ = kMGroups * 8u;        // 384 float4: the f32 part
+constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 768 float4 = 12 KB
+static_assert(kMTileQ % 256u == 0u, "whole workgroup LDS-DMA passes");
+SP_DEV constexpr uint32_t cylm_slot(uint32_t group, uint32_t chunk) { return chunk * kMGroups + group; }
+
+// length scale of the scene: the power of two in [2 Rv, 4 Rv); 0 = matrix filter off for this scene (Rv outside [1e-30, 1e30])
+SP_DEV float cylm_scale(float rv) {
+	if (!(rv > 1e-30f && rv < 1e30f)) return 0.0f;
+	const uint32_t e = (__float_as_uint(rv) >> 23) & 255u;        // rv in [2^(e-127), 2^(e-126))
+	return __uint_as_float((e + 2u) << 23);
+}
+
+SP_DEV void half_split(float v, _Float16& hi, _Float16& lo) {
+	hi = (_Float16)v;
+	lo = (_Float16)(v - (float)hi);
+}
+
+// triangle `in_tile` of a tile: f32 part as cyl_store (48 groups), scaled H^ into chunk 7, the A-fragment row
+SP_DEV void cylm_store(float4* __restrict__ tile, uint32_t in_tile, const float4 q0, const float4 q1, float S) {
+	const uint32_t grp = in_tile >> 2, u = in_tile & 3u;
+	tile[cylm_slot(grp, u)] = q0;
+	float* mh = (float*)(tile + cylm_slot(grp, 4u + (u >> 1))) + 2u * (u & 1u);
+	mh[0] = q1.x; mh[1] = q1.y;
+	((float*)(tile + cylm_slot(grp, 6u)))[u] = q1.z;
+	const float k = S > 0.0f ? 256.0f / S : 1.0f, m = S > 0.0f ? 16.0f / S : 0.0f;      // exact: S is a power of two
+	((float*)(tile + cylm_slot(grp, 7u)))[u] = q1.y * k;                                // +-inf stay +-inf
+	_Float16 bh, bl, ch, cl, xh, xl, yh, yl, zh, zl;
+	half_split(S > 0.0f ? 16.0f * q0.x : 0.0f, bh, bl); half_split(S > 0.0f ? 16.0f * q0.y : 0.0f, ch, cl);
+	half_split(q0.z * m, xh, xl); half_split(q0.w * m, yh, yl); half_split(q1.x * m, zh, zl);
+	const _Float16 z = (_Float16)0.0f;
+	const half8 k0 = { bh, bl, bh, ch, cl, ch, xh, xl }, k1 = { xh, yh, yl, yh, zh, zl, zh, S > 0.0f ? (_Float16)16.0f : z };
+	half8* frag = (half8*)(tile + kMRecQ) + (in_tile >> 5) * 64u + (in_tile & 31u);      // lane = row (h = 0), row + 32 (h = 1)
+	frag[0] = k0; frag[32] = k1;
+}
+
+__global__ void __launch_bounds__(256) k_cylm_scatter(const float* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ block_offsets,
+                                                     const uint32_t* __restrict__ hdr, const unsigned int* __restrict__ bounds, float4* __restrict__ rec) {
+	__shared__ uint32_t wave_cnt[4][3];
+	const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid, wv = tid >> 6, lane = tid & 63u;
+	const float S = cylm_scale(__uint_as_float(bounds[0]));
+	float4 q0, q1;
+	q0 = q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const int cls = i < n ? cyl_record(tris + (size_t)i * 12, i, q0, q1) : -1;
+	uint32_t rank = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const unsigned long long m = __ballot(cls == k);
+		if (cls == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		if (lane == 0) wave_cnt[wv][k] = (uint32_t)__popcll(m);
+	}
+	__syncthreads();
+	if (cls >= 0) {
+		for (uint32_t v = 0; v < wv; ++v) rank += wave_cnt[v][cls];
+		const size_t pos = (size_t)hdr[3 + cls] * kMTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
+		const size_t tile = pos / kMTile;
+		cylm_store(rec + tile * kMTileQ, (uint32_t)(pos - tile * kMTile), q0, q1, S);
+	}
+}
+
+__global__ void __launch_bounds__(256) k_cylm_pad(uint32_t* __restrict__ hdr, uint32_t n_tris, const unsigned int* __restrict__ bounds, float4* __restrict__ rec) {
+	const uint32_t k = blockIdx.x, tid = threadIdx.x;
+	const uint32_t n = hdr[k], first = hdr[3 + k] * kMTile;
+	const float S = cylm_scale(__uint_as_float(bounds[0]));
+	for (uint32_t pos = n + tid; pos < (n + kMTile - 1u) / kMTile * kMTile; pos += 256u) {
+		const size_t gpos = (size_t)first + pos, tile = gpos / kMTile;
+		cylm_store(rec + tile * kMTileQ, (uint32_t)(gpos - tile * kMTile), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+		           make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f), S);
+	}
+	if (k == 0 && tid == 0) ((float*)hdr)[7] = S;            // the scan reads the scale next to the class table
+}
+
+SP_DEV void cylm_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, uint32_t wbase) {
+	typedef __attribute__((address_space(1))) const void* gptr_t;
+	typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+	for (int p = 0; p < (int)(kMTileQ / 256u); ++p)
+		__builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + tid), (lptr_t)(dst + p * 256 + wbase), 16, 0, 0);
+}
+
+struct CylmGroup { float4 q0[4]; float4 mh01, mh23; };
+SP_DEV CylmGroup cylm_group(const float4* tile, uint32_t grp) {
+	CylmGroup G;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) G.q0[u] = tile[cylm_slot(grp, (uint32_t)u)];
+	G.mh01 = tile[cylm_slot(grp, 4u)]; G.mh23 = tile[cylm_slot(grp, 5u)];
+	return G;
+}
+
+constexpr uint32_t kMCap = 512u;             // list entries per wave and pass (16 bits each: ray << 6 | group)
+
+// Closest hit for the ray of every lane.  Block-uniform call (barriers inside).
+SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlots<1>& s, float (&bd)[1], int (&bi)[1]) {
+	__shared__ float4 sm[2 * kMTileQ];
+	__shared__ unsigned short lst[4 * kMCap];
+	__shared__ uint32_t lcnt[4];
+	__shared__ unsigned long long cell[256];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u, hh = lane >> 5;
+	unsigned short* const mylst = lst + (tid >> 6) * kMCap;
+	uint32_t* const mycnt = lcnt + (tid >> 6);
+	const float S = ((const float*)cs.hdr)[7];
+
+	// ---- the lane's own ray: the f32 filter state of cyl_setup (stage 2 recomputes x in f32) and its scaled halves
+	CylRay<1> f;
+	cyl_setup<1>(rv, s, f);
+	const float adx = fabsf(s.dir[0].x), ady = fabsf(s.dir[0].y), adz = fabsf(s.dir[0].z);
+	const float on = fabsf(s.o[0].x) + fabsf(s.o[0].y) + fabsf(s.o[0].z);
+	const float dmax = fmaxf(adx, fmaxf(ady, adz));
+	// cyl_setup's verdict (filter on: finite margin) plus the range of the halves; off: zero operands and a margin of +inf
+	const bool on_m = (f.Dq[0] < __builtin_inff()) && (f.Dq[0] > 0.0f) && (S > 0.0f) && (on + 2.0f * rv <= 512.0f * S);
+	const uint32_t ed = (__float_as_uint(dmax) >> 23) & 255u;
+	const float s_d = on_m ? __uint_as_float((254u - ed) << 23) : 0.0f;                 // 2^-(e-127): dmax * s_d in [1, 2)
+	const float kP = on_m ? s_d * (16.0f / S) : 0.0f, kN = 16.0f * s_d, kC = on_m ? s_d * (256.0f / S) : 0.0f;
+	const float Dh = on_m ? f.D[0] * s_d : 1.0f;
+	// inactive lane: Dq = -inf (rejected); filter off: +inf; else scaled (exact)
+	const float Dqh = on_m ? f.Dq[0] * kC : (s.act[0] ? __builtin_inff() : -__builtin_inff());
+	// world-frame scaled values; the class rotation below picks (a, b, c) = (x, y, z), (y, z, x), (z, x, y)
+	const float Pw[3] = { f.Pa[0] * kP, f.Pb[0] * kP, f.Pc[0] * kP };                  // cyl_setup leaves class 0: (Pa, Pb, Pc) = (P.x, P.y, P.z)
+	const float Nw[3] = { f.ndx[0] * kN, f.ndy[0] * kN, f.ndz[0] * kN };
+
+	const unsigned long long kNone = ((unsigned long long)__float_as_uint(kMaxDist) << 32) | 0xffffffffull;
+	cell[tid] = kNone;
+
+	// B fragments, D^ and Dq^ of the two ray blocks for class `cls` (lane l: column l & 31 of block rb, K half l >> 5)
+	half8 bfr[2];
+	float Dn[2], Dqn[2];
+	auto build_b = [&](uint32_t cls) {
+		const float Pa_ = cls == 0u ? Pw[0] : cls == 1u ? Pw[1] : Pw[2];
+		const float Pb_ = cls == 0u ? Pw[1] : cls == 1u ? Pw[2] : Pw[0], Pc_ = cls == 0u ? Pw[2] : cls == 1u ? Pw[0] : Pw[1];
+		// scale the ray by t so that its P_a is exactly a half
+		const _Float16 ah = (_Float16)Pa_;
+		const float fa = (float)ah;
+		const bool big = fabsf(Pa_) >= 0x1p-10f;
+		const float t = big ? fa / Pa_ : 1.0f;
+		const float extra = big ? 0.0f : fabsf(Pa_ - fa) * 16.0f;                        // the slot's weight on the triangle side is 16
+		_Float16 bh, bl, ch, cl, nh[3], nl[3];
+		half_split(Pb_ * t, bh, bl); half_split(Pc_ * t, ch, cl);
+		half_split(Nw[0] * t, nh[0], nl[0]); half_split(Nw[1] * t, nh[1], nl[1]); half_split(Nw[2] * t, nh[2], nl[2]);
+		const half8 k0 = { bh, bh, bl, ch, ch, cl, nh[0], nh[0] };
+		const half8 k1 = { nl[0], nh[1], nh[1], nl[1], nh[2], nh[2], nl[2], ah };
+		const float Dt = Dh * t;                                                         // D carries 2^-21 of slack: a rounding costs 2^-24
+		const float Dqt = on_m ? (Dqh * t + extra) * (1.0f + 0x1p-20f) : Dqh;            // +-inf as they are
+		typedef int int4v __attribute__((ext_vector_type(4)));
+		const int4v v0 = __builtin_bit_cast(int4v, k0), v1 = __builtin_bit_cast(int4v, k1);
+#pragma unroll
+		for (int rb = 0; rb < 2; ++rb) {
+			const int src = (int)((lane & 31u) + 32u * (uint32_t)rb);
+			int4v o;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) { const int va = __shfl(v0[c], src, 64), vb = __shfl(v1[c], src, 64); o[c] = hh ? vb : va; }
+			bfr[rb] = __builtin_bit_cast(half8, o);
+			Dn[rb] = __shfl(Dt, src, 64);
+			Dqn[rb] = __shfl(Dqt, src, 64);
+		}
+	};
+	build_b(0u);
+
+	const uint32_t total_tiles = cs.hdr[6];
+	uint32_t cls = 0;
+	__syncthreads();                                  // readers of the previous scan are done with sm
+	cylm_tile_dma(cs.rec, sm, tid, wbase);
+	__syncthreads();
+	for (uint32_t gt = 0; gt < total_tiles; ++gt) {
+		while (cls < 2u && gt >= cs.hdr[4 + cls]) {
+			++cls;
+			// f32 state of stage 2 rotates as in scan_cylw; the halves are rebuilt for the class
+			const float t0 = f.Pa[0]; f.Pa[0] = f.Pb[0]; f.Pb[0] = f.Pc[0]; f.Pc[0] = t0;
+			build_b(cls);
+		}
+		const float4* cur = sm + (gt & 1u) * kMTileQ;
+		const half8* frags = (const half8*)(cur + kMRecQ);
+		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kMTile;
+		const uint32_t nblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kMTile ? left : kMTile) + 31u) / 32u));
+		// ---- stage 1: word[rb] gets 4 bits per fragment (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
+		uint32_t word[2] = { 0u, 0u };
+		float16v zero;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+		for (uint32_t tb = 0; tb < nblk; ++tb) {
+			const half8 afr = frags[tb * 64u + lane];
+			float4 Hq[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) Hq[j] = cur[cylm_slot(tb * 8u + 2u * (uint32_t)j + hh, 7u)];
+			const float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[0], zero, 0, 0, 0);
+			const float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[1], zero, 0, 0, 0);
+#pragma unroll
+			for (int rb = 0; rb < 2; ++rb) {
+				const float16v& g = rb == 0 ? g0 : g1;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const float x0 = __builtin_fmaf(-Hq[j].x, Dn[rb], __builtin_fabsf(g[4 * j + 0])), x1 = __builtin_fmaf(-Hq[j].y, Dn[rb], __builtin_fabsf(g[4 * j + 1]));
+					const float x2 = __builtin_fmaf(-Hq[j].z, Dn[rb], __builtin_fabsf(g[4 * j + 2])), x3 = __builtin_fmaf(-Hq[j].w, Dn[rb], __builtin_fabsf(g[4 * j + 3]));
+					const float m = __builtin_fminf(__builtin_fminf(x0, x1), __builtin_fminf(x2, x3));
+					word[rb] = __builtin_amdgcn_alignbit(word[rb], __float_as_uint(m - Dqn[rb]), 31);
+				}
+			}
+		}
+		const uint32_t done = nblk * 4u;                              // bits appended; left-align
+#pragma unroll
+		for (int rb = 0; rb < 2; ++rb) word[rb] = done == 0u ? 0u : (word[rb] << (32u - done));
+		// the next tile streams in while the survivors are resolved
+		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, sm + ((gt + 1u) & 1u) * kMTileQ, tid, wbase);
+		// ---- stage 2: one list per wave; entry = (ray = donor lane) << 6 | group
+		for (;;) {
+			const uint32_t c = (uint32_t)__builtin_popcount(word[0]) + (uint32_t)__builtin_popcount(word[1]);
+			if (!__any(c != 0u)) break;
+			if (lane == 0) *mycnt = 0u;
+			uint32_t j = c ? atomicAdd(mycnt, c) : 0u;
+			const uint32_t jend = j + c < kMCap ? j + c : kMCap;
+#pragma unroll
+			for (int rb = 0; rb < 2; ++rb) {
+				uint32_t m = word[rb];
+				const uint32_t ray = (lane & 31u) + 32u * (uint32_t)rb;
+				while (__any(m != 0u && j < jend)) {
+					if (m != 0u && j < jend) {
+						const uint32_t e = (uint32_t)__builtin_clz(m);                      // e-th appended bit: fragment e / 4, j = e % 4
+						mylst[j++] = (unsigned short)((ray << 6) | ((e >> 2) * 8u + 2u * (e & 3u) + hh));
+						m &= ~(0x80000000u >> e);
+					}
+				}
+				word[rb] = m;
+			}
+			uint32_t total = *mycnt;
+			total = (uint32_t)__builtin_amdgcn_readfirstlane((int)(total < kMCap ? total : kMCap));
+#ifdef SP_FILTER_STATS
+			if (lane == 0) { atomicAdd(a.scans + 1, (unsigned long long)total); atomicAdd(a.scans + 2, (unsigned long long)((total + 63u) / 64u)); }
+#endif
+			for (uint32_t base = 0; base < total; base += 64u) {
+				const uint32_t ent = base + lane;
+				const bool ok = ent < total;
+				const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 6);
+				const int L = (int)(entry >> 6);
+				const uint32_t grp = entry & 63u;
+				const float ox = __shfl(s.o[0].x, L, 64), oy = __shfl(s.o[0].y, L, 64), oz = __shfl(s.o[0].z, L, 64);
+				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
+				const int src = __shfl(s.src[0], L, 64);
+				const float Pa = __shfl(f.Pa[0], L, 64), Pb = __shfl(f.Pb[0], L, 64), Pc = __shfl(f.Pc[0], L, 64);
+				const float D = __shfl(f.D[0], L, 64), Dq = __shfl(f.Dq[0], L, 64);
+				// the f32 cylinder test of sp_cyl_scan.h on the group's four records: which of them survive
+				uint32_t cand = 0;
+				const CylmGroup G = cylm_group(cur, grp);
+				const float4 gi = cur[cylm_slot(grp, 6u)];
+				const int idx4[4] = { (int)__float_as_uint(gi.x), (int)__float_as_uint(gi.y), (int)__float_as_uint(gi.z), (int)__float_as_uint(gi.w) };
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const float mz = u == 0 ? G.mh01.x : u == 1 ? G.mh01.z : u == 2 ? G.mh23.x : G.mh23.z;
+					const float Hh = u == 0 ? G.mh01.y : u == 1 ? G.mh01.w : u == 2 ? G.mh23.y : G.mh23.w;
+					const float x = cyl_x(G.q0[u], mz, Hh, Pa, Pb, Pc, -dx, -dy, -dz, D);
+					cand |= (ok && !(x - Dq >= 0.0f)) ? (1u << u) : 0u;
+				}
+				while (__any(cand != 0u)) {
+#ifdef SP_FILTER_STATS
+					if (lane == 0) atomicAdd(a.scans + 5, 1ull);
+#endif
+					if (cand != 0u) {
+						const uint32_t low = cand & (0u - cand);
+						cand ^= low;
+						const int idx = (low & 1u) ? idx4[0] : (low & 2u) ? idx4[1] : (low & 4u) ? idx4[2] : idx4[3];
+#ifdef SP_FILTER_STATS
+						atomicAdd(a.scans + 4, 1ull);
+#endif
+						const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
+						const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+						if ((d > 0.0f) && (d < kMaxDist) && (idx != src))
+							atomicMin(&cell[(int)wbase + L], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)idx);
+					}
+				}
+			}
+		}
+#ifdef SP_FILTER_STATS
+		if (lane == 0) atomicAdd(a.scans + 3, 1ull);
+#endif
+		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
+	}
+	const unsigned long long k = cell[tid];
+	bd[0] = __uint_as_float((uint32_t)(k >> 32));
+	bi[0] = (int)(uint32_t)k;
+}
+
+} // namespace sp

@@ -1,21 +1,25 @@
 // Kernels over the two-stage scans: the closest-hit scan alone, renderer::render_flat, renderer::render.
 // SCAN = 0: sp_filter_scan.h (slab filter, per-lane LDS queues)     SCAN = 1: sp_cyl_scan.h (cylinder filter, bit words, stage 2 per lane)
 // SCAN = 2: sp_cyl_scan.h scan_cylw (the same stage 1, stage 2 shared by the wave)
+// SCAN = 3: sp_cylm_scan.h scan_cylm (stage 1 on the f16 matrix pipe, one ray per lane, stage 2 shared by the wave)
 #pragma once
 
 #include "sp_filter_scan.h"
 #include "sp_cyl_scan.h"
+#include "sp_cylm_scan.h"
 
 namespace sp {
 
 struct ScanSrc {
 	const float4* filt;      // slab records (k_repack_filter)
 	CylStream cyl;           // cylinder records (k_cyl_scatter)
+	CylStream cylm;          // cylinder records + matrix fragments (k_cylm_scatter)
 };
 
 template <int R, int SCAN>
 SP_DEV void two_stage_scan(const KArgs& a, const ScanSrc& src, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
-	if (SCAN == 2) scan_cylw<R>(a, src.cyl, rv, s, bd, bi);
+	if constexpr (SCAN == 3) { static_assert(R == 1, "scan_cylm: one ray per lane"); scan_cylm(a, src.cylm, rv, s, bd, bi); }
+	else if (SCAN == 2) scan_cylw<R>(a, src.cyl, rv, s, bd, bi);
 	else if (SCAN == 1) scan_cyl<R>(a, src.cyl, rv, s, bd, bi);
 	else scan_filter<R>(a, src.filt, rv, s, bd, bi);
 }

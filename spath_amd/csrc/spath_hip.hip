@@ -40,7 +40,7 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, bvh_sort, bvh_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, bvh_sort, bvh_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim, cylm_rec, cylm_cnt, cylm_hdr;
 	bool bvh_valid = false;
 	uint32_t bvh_leaves = 0;
 	size_t n_tris = 0;
@@ -91,18 +91,18 @@ int ensure(sphip_ctx* c, DevBuf& b, size_t bytes) {
 
 // kernel variants selectable through the low byte of `flags` (sphip_kernel_name); all brute force except 8
 constexpr int kVariantAccel = 8;          // the opt-in acceleration structure (SPHIP_FLAG_ACCEL)
-constexpr int kVariantLast = 15;
+constexpr int kVariantLast = 16;
 constexpr uint64_t kChunkTargetBlocks = 262144;         // 256 x the 1024 resident workgroups (measured: profiles/r01_sample_chunks.log)
 constexpr uint64_t kChunkMaxBytes = 16ull << 30;         // cap of the per-sample scratch buffer
 const char* const kVariantNames[kVariantLast + 1] = { "auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_filter4", "rpl_filter1", "rpl_filter2s", "rpl_filter4s",
-                                                      "accel_lbvh", "rpl_cyl1", "rpl_cyl2", "rpl_cyl4", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4", "rpl_cylw4s" };
+                                                      "accel_lbvh", "rpl_cyl1", "rpl_cyl2", "rpl_cyl4", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4", "rpl_cylw4s", "rpl_cylm" };
 
 // the two-stage scan variants: paths per lane (R), whether the R paths are consecutive samples of ONE pixel (split) or R
 // pixels, and the scan generation (0 = slab filter + LDS queues, sp_filter_scan.h; 1 = cylinder filter + bit words, sp_cyl_scan.h)
 struct TwoStage { int R; bool split; int scan; };
 bool two_stage(int variant, TwoStage* out) {
 	static const TwoStage tab[kVariantLast + 1] = { {0, false, 0}, {0, false, 0}, {0, false, 0}, {2, false, 0}, {4, false, 0}, {1, false, 0}, {2, true, 0}, {4, true, 0},
-	                                                {0, false, 0}, {1, false, 1}, {2, false, 1}, {4, false, 1}, {2, true, 1}, {4, true, 1}, {4, false, 2}, {4, true, 2} };
+	                                                {0, false, 0}, {1, false, 1}, {2, false, 1}, {4, false, 1}, {2, true, 1}, {4, true, 1}, {4, false, 2}, {4, true, 2}, {1, false, 3} };
 	if (variant < 0 || variant > kVariantLast || tab[variant].R == 0) return false;
 	if (out) *out = tab[variant];
 	return true;
@@ -142,10 +142,18 @@ int repack(sphip_ctx* c, hipStream_t st) {
 		if ((rc = ensure(c, c->cyl_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cyl_hdr, 256)) ||
 		    (rc = ensure(c, c->cyl_rec, ((size_t)n / sp::kCylTile + 4) * sp::kCylTile * 32))) return rc;
 		hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cyl_cnt.p);
-		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cyl_cnt.p, nblocks, (uint32_t*)c->cyl_hdr.p);
+		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cyl_cnt.p, nblocks, (uint32_t*)c->cyl_hdr.p, sp::kCylTile);
 		hipLaunchKernelGGL(sp::k_cyl_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cyl_cnt.p,
 		                   (const uint32_t*)c->cyl_hdr.p, (float4*)c->cyl_rec.p);
 		hipLaunchKernelGGL(sp::k_cyl_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)c->cyl_hdr.p, n, (float4*)c->cyl_rec.p);
+		// the same classes in 192-triangle tiles with the f16 matrix fragments (sp_cylm_scan.h)
+		if ((rc = ensure(c, c->cylm_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cylm_hdr, 256)) ||
+		    (rc = ensure(c, c->cylm_rec, ((size_t)n / sp::kMTile + 4) * sp::kMTileQ * 16))) return rc;
+		hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cylm_cnt.p);
+		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cylm_cnt.p, nblocks, (uint32_t*)c->cylm_hdr.p, sp::kMTile);
+		hipLaunchKernelGGL(sp::k_cylm_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cylm_cnt.p,
+		                   (const uint32_t*)c->cylm_hdr.p, (const unsigned int*)c->bounds.p, (float4*)c->cylm_rec.p);
+		hipLaunchKernelGGL(sp::k_cylm_pad, dim3(3), dim3(256), 0, st, (uint32_t*)c->cylm_hdr.p, n, (const unsigned int*)c->bounds.p, (float4*)c->cylm_rec.p);
 		HIP_TRY(c, hipGetLastError());
 	}
 	c->have_scene = true;
@@ -285,6 +293,8 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	src2.filt = (const float4*)c->filt.p;
 	src2.cyl.rec = (const float4*)c->cyl_rec.p;
 	src2.cyl.hdr = (const uint32_t*)c->cyl_hdr.p;
+	src2.cylm.rec = (const float4*)c->cylm_rec.p;
+	src2.cylm.hdr = (const uint32_t*)c->cylm_hdr.p;
 	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
 	sp::BvhArgs B{};
 	if (variant == kVariantAccel) {
@@ -304,6 +314,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		const int* no_src = nullptr;
 #define SP_PRIM(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, h, src2, bnd, no_src, oi, od)
 		if (ts.scan == 0) { if (ts.R == 4) SP_PRIM(4, 0); else if (ts.R == 2) SP_PRIM(2, 0); else SP_PRIM(1, 0); }
+		else if (ts.scan == 3) SP_PRIM(1, 3);
 		else if (ts.scan == 2) SP_PRIM(4, 2);
 		else              { if (ts.R == 4) SP_PRIM(4, 1); else if (ts.R == 2) SP_PRIM(2, 1); else SP_PRIM(1, 1); }
 #undef SP_PRIM
@@ -319,6 +330,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		if (is_ts) {
 #define SP_HIT(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd, d_src, oi, od)
 			if (ts.scan == 0) { if (ts.R == 4) SP_HIT(4, 0); else if (ts.R == 2) SP_HIT(2, 0); else SP_HIT(1, 0); }
+			else if (ts.scan == 3) SP_HIT(1, 3);
 			else if (ts.scan == 2) SP_HIT(4, 2);
 			else              { if (ts.R == 4) SP_HIT(4, 1); else if (ts.R == 2) SP_HIT(2, 1); else SP_HIT(1, 1); }
 #undef SP_HIT
@@ -329,6 +341,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		if (is_ts) {
 #define SP_FLAT(R_, S_) hipLaunchKernelGGL((sp::k_flat_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd)
 			if (ts.scan == 0) { if (ts.R == 4) SP_FLAT(4, 0); else if (ts.R == 2) SP_FLAT(2, 0); else SP_FLAT(1, 0); }
+			else if (ts.scan == 3) SP_FLAT(1, 3);
 			else if (ts.scan == 2) SP_FLAT(4, 2);
 			else              { if (ts.R == 4) SP_FLAT(4, 1); else if (ts.R == 2) SP_FLAT(2, 1); else SP_FLAT(1, 1); }
 #undef SP_FLAT
@@ -341,6 +354,8 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 			if (ts.scan == 0) {
 				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 0); else SP_PT(2, true, 0); }
 				else          { if (ts.R == 4) SP_PT(4, false, 0); else if (ts.R == 2) SP_PT(2, false, 0); else SP_PT(1, false, 0); }
+			} else if (ts.scan == 3) {
+				SP_PT(1, false, 3);
 			} else if (ts.scan == 2) {
 				if (ts.split) SP_PT(4, true, 2); else SP_PT(4, false, 2);
 			} else {
@@ -763,8 +778,8 @@ void sphip_destroy(sphip_t* c) {
 	}
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[21] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
-	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->bvh_sort, &c->bvh_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim };
+	DevBuf* bufs[24] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->bvh_sort, &c->bvh_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim, &c->cylm_rec, &c->cylm_cnt, &c->cylm_hdr };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);

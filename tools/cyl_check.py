@@ -6,7 +6,7 @@ import numpy as np, torch
 from spath_amd import capi, scene, view
 from oracle import oracle as O
 
-NEW = [9, 10, 11, 12, 13, 14, 15]
+NEW = [9, 10, 11, 12, 13, 14, 15, 16]
 names = {v: k for k, v in capi.kernel_variants().items()}
 ctx = capi.Context(0)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
