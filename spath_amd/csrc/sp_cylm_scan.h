@@ -41,12 +41,17 @@ namespace sp {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr uint32_t kMTile = 192u;                 // triangles per tile
+#ifndef SP_CYLM_TILE
+#define SP_CYLM_TILE 256
+#endif
+
+constexpr uint32_t kMTile = SP_CYLM_TILE;        // triangles per tile
 constexpr uint32_t kMGroups = kMTile / 4u;        // 48
 constexpr uint32_t kMBlocks = kMTile / 32u;       // 6 fragments
 constexpr uint32_t kMRecQ = kMGroups * 8u;        // 384 float4: the f32 part
 constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 768 float4 = 12 KB
 static_assert(kMTileQ % 256u == 0u, "whole workgroup LDS-DMA passes");
+static_assert(kMGroups <= 64u && kMBlocks * 4u <= 32u, "6-bit group index in a list entry; one 32-bit word of group bits per ray block");
 SP_DEV constexpr uint32_t cylm_slot(uint32_t group, uint32_t chunk) { return chunk * kMGroups + group; }
 
 // length scale of the scene: the power of two in [2 Rv, 4 Rv); 0 = matrix filter off for this scene (Rv outside [1e-30, 1e30])
@@ -202,6 +207,9 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 
 	const uint32_t total_tiles = cs.hdr[6];
 	uint32_t cls = 0;
+#ifdef SP_EXP_NO_STAGE2
+	uint32_t exp_acc = 0;
+#endif
 	__syncthreads();                                  // readers of the previous scan are done with sm
 	cylm_tile_dma(cs.rec, sm, tid, wbase);
 	__syncthreads();
@@ -246,7 +254,12 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		// the next tile streams in while the survivors are resolved
 		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, sm + ((gt + 1u) & 1u) * kMTileQ, tid, wbase);
 		// ---- stage 2: one list per wave; entry = (ray = donor lane) << 6 | group
+#ifdef SP_EXP_NO_STAGE2
+		exp_acc ^= word[0] ^ word[1];
+		for (; false;) {
+#else
 		for (;;) {
+#endif
 			const uint32_t c = (uint32_t)__builtin_popcount(word[0]) + (uint32_t)__builtin_popcount(word[1]);
 			if (!__any(c != 0u)) break;
 			if (lane == 0) *mycnt = 0u;
@@ -317,6 +330,9 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 #endif
 		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
 	}
+#ifdef SP_EXP_NO_STAGE2
+	if (exp_acc == 0x12345678u) cell[tid] = 0ull;
+#endif
 	const unsigned long long k = cell[tid];
 	bd[0] = __uint_as_float((uint32_t)(k >> 32));
 	bi[0] = (int)(uint32_t)k;

@@ -113,13 +113,11 @@ int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_sam
 	const int v = flags & SPHIP_KERNEL_MASK;
 	if (v >= 1 && v <= kVariantLast) return v;
 	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
-	// Path tracing with >= 2 spp: consecutive SAMPLES of a pixel share a lane (a record read from LDS serves all of them; a
-	// workgroup still covers 256 pixels, and sample chunks (launch_render) supply the workgroups a small frame lacks).
-	// One scan per ray (flat pass, 1 spp): pixels share a lane when that still leaves >= ~768 workgroups.
-	// Four paths per lane run the wave-shared stage 2 (sp_cyl_scan.h: scan_cylw), fewer the per-lane one.
-	if (mode == SPHIP_MODE_PT && n_samples >= 4) return 15;
-	if (mode == SPHIP_MODE_PT && n_samples >= 2) return 12;
-	return n_rays >= 768u * 1024u ? 14 : (n_rays >= 384u * 1024u ? 10 : 9);
+	// The third-generation scan (sp_cylm_scan.h: stage 1 on the f16 matrix pipe, one ray per lane) for every mode; sample chunks
+	// (launch_render) supply the workgroups a small frame lacks.  The earlier generations stay selectable through the flags:
+	// 15 / 12 = 4 / 2 consecutive samples of a pixel per lane with the f32 VALU stage 1 (14 / 10 / 9 for one scan per ray).
+	(void)n_rays; (void)mode; (void)n_samples;
+	return 16;
 }
 
 int repack(sphip_ctx* c, hipStream_t st) {

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.load()
     assert L.sphip_abi_version() == 2
     assert L.sphip_kernel_name(0) == b"auto" and L.sphip_kernel_name(99) is None
-    assert set(capi.kernel_variants()) >= {"auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4s"}
+    assert set(capi.kernel_variants()) >= {"auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4s", "rpl_cylm"}
 
 
 def test_no_device_is_a_loud_error_not_a_fallback():

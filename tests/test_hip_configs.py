@@ -49,14 +49,14 @@ def test_4k_row_tile_slice_exact_scan_and_oracle(hip, O, n_tris, spp, band_px):
     hip.set_scene_device(d_t.data_ptr(), d_m.data_ptr(), n_tris, torch.cuda.current_stream().cuda_stream)
     shard = plan.shard(0)
     a_img, a_acc, a_st = _render_shard(hip, d_rays, n, shard, w, spp, seed, 0)
-    assert a_st["kernel_variant"] in (12, 15), a_st        # the library's own choice: a cylinder-filter scan
+    assert a_st["kernel_variant"] == 16, a_st        # the library's own choice: the cylinder filter on the f16 matrix pipe
     b_img, b_acc, b_st = _render_shard(hip, d_rays, n, shard, w, spp, seed, EXACT)
     assert b_st["kernel_variant"] == EXACT
     assert np.array_equal(a_img, b_img) and np.array_equal(a_acc, b_acc)
     assert a_st["scans_executed"] == b_st["scans_executed"]
     assert abs(a_st["scans_executed"] - n * spp * 5) <= 2e-4 * n * spp * 5      # closed room: nominal == executed up to edge leaks
-    # the first-generation slab-filter scan (rpl_filter2s) and the per-lane stage 2 of the cylinder scan (rpl_cyl4s / rpl_cyl2s) as well
-    for var in (6, 13 if spp >= 4 else 12):
+    # the first-generation slab-filter scan (rpl_filter2s) and the f32 cylinder scans (wave-shared and per-lane stage 2) as well
+    for var in (6, 15, 13 if spp >= 4 else 12):
         c_img, c_acc, c_st = _render_shard(hip, d_rays, n, shard, w, spp, seed, var)
         assert np.array_equal(c_img, b_img) and np.array_equal(c_acc, b_acc) and c_st["scans_executed"] == b_st["scans_executed"], var
     # oracle on a band in the second tile of the slice: frame rows 64.., i.e. global pixel keys far from the local indices
@@ -76,14 +76,14 @@ def test_configs2_real_launch_shape_256spp(hip, O):
     d_rays, d_t, d_m = _dev(rays), _dev(t), _dev(m)
     hip.set_scene_device(d_t.data_ptr(), d_m.data_ptr(), 10000, torch.cuda.current_stream().cuda_stream)
     a_img, a_acc, a_st = _render_shard(hip, d_rays, w * h, None, w, spp, seed, 0)
-    assert a_st["n_launches"] == 2 and a_st["kernel_variant"] == 15            # sample-chunked rpl_cylw4s + resolve
+    assert a_st["n_launches"] == 2 and a_st["kernel_variant"] == 16            # sample-chunked rpl_cylm + resolve
     b_img, b_acc, b_st = _render_shard(hip, d_rays, w * h, None, w, spp, seed, capi.flag_chunks(1))
     assert b_st["n_launches"] == 1
     assert np.array_equal(a_img, b_img) and np.array_equal(a_acc, b_acc) and a_st["scans_executed"] == b_st["scans_executed"]
     assert abs(a_st["scans_executed"] - w * h * spp * 5) <= 1e-5 * w * h * spp * 5
     # SURVEY 8(f3), opt-in: the primary hit of each pixel from a one-scan-per-pixel pre-pass -- same bits, 1/5 fewer scans
     c_img, c_acc, c_st = _render_shard(hip, d_rays, w * h, None, w, spp, seed, capi.FLAG_PRIMARY_REUSE)
-    assert c_st["n_launches"] == 3 and c_st["kernel_variant"] == 15
+    assert c_st["n_launches"] == 3 and c_st["kernel_variant"] == 16
     assert np.array_equal(a_img, c_img) and np.array_equal(a_acc, c_acc)
     assert c_st["scans_executed"] == a_st["scans_executed"] - w * h * (spp - 1)
     p0, n = 540 * w + 700, 256

@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 
 ACCUM_LINF_TOLERANCE = 0.0          # float accumulators: exact
 # rpl_sload, rpl_lds; slab-filter scans rpl_filter2/4/1/2s/4s; cylinder-filter scans rpl_cyl1/2/4/2s/4s (8 is the opt-in acceleration structure)
-VARIANTS = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15]      # 14, 15: cylinder filter with the wave-shared stage 2
-TWO_STAGE = [3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15]
+VARIANTS = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16]      # 14, 15: wave-shared stage 2; 16: stage 1 on the f16 matrix pipe
+TWO_STAGE = [3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16]
 
 
 def dev(a):

@@ -7,7 +7,7 @@ import torch
 from spath_amd import capi, scene, view
 
 pytestmark = pytest.mark.gpu
-VARIANTS = [1, 2, 3, 5, 6, 9, 10, 12, 13, 14, 15]
+VARIANTS = [1, 2, 3, 5, 6, 9, 10, 12, 13, 14, 15, 16]
 
 
 def _hits(hip, O, t, rays, tag):

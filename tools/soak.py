@@ -10,7 +10,7 @@ from spath_amd import capi, scene, view
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 ctx = capi.Context(0)
-TWO = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15]
+TWO = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16]
 names = {v: k for k, v in capi.kernel_variants().items()}
 
 
