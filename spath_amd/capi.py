@@ -251,7 +251,7 @@ class Context:
                                                 acc.ctypes.data if want_accum else None), "sphip_render_camera")
         return (out, acc) if want_accum else out
 
-    SELFTEST_OUT = {0: ("float32", 2), 1: ("float32", 1), 2: ("float64", 2), 3: ("float32", 3), 4: ("float32", 1), 5: ("uint32", 1)}
+    SELFTEST_OUT = {0: ("float32", 2), 1: ("float32", 1), 2: ("float64", 2), 3: ("float32", 3), 4: ("float32", 1), 5: ("uint32", 1), 6: ("float32", 2)}
 
     def selftest(self, what: int, inp, n: int):
         """sphip_selftest_device (test-only): one device function of the path on n caller-supplied inputs."""

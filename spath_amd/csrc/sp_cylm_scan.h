@@ -61,9 +61,19 @@ SP_DEV float cylm_scale(float rv) {
 	return __uint_as_float((e + 2u) << 23);
 }
 
+// float -> half, ONCE: the value that goes into a fragment must be the very value its remainder (or the scale t) was computed
+// from.  Without the barrier the compiler converts again where the fragment is assembled (v_cvt_pk_f16_f32 next to the
+// v_cvt_f16_f32 used for the remainder), and the two instructions do not round a near-tie the same way: hi and lo then
+// belong to different splittings and the product is off by an ulp of the half (found by tools/soak.py on aimed rays).
+SP_DEV _Float16 to_half(float v) {
+	uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v);
+	__asm__ volatile("" : "+v"(b));
+	return __builtin_bit_cast(_Float16, (unsigned short)b);
+}
+
 SP_DEV void half_split(float v, _Float16& hi, _Float16& lo) {
-	hi = (_Float16)v;
-	lo = (_Float16)(v - (float)hi);
+	hi = to_half(v);
+	lo = to_half(v - (float)hi);
 }
 
 // triangle `in_tile` of a tile: f32 part as cyl_store (48 groups), scaled H^ into chunk 7, the A-fragment row
@@ -137,6 +147,35 @@ SP_DEV CylmGroup cylm_group(const float4* tile, uint32_t grp) {
 	return G;
 }
 
+// ---- test-only (sphip_selftest_device, what = 6): the side product of ONE (triangle, ray) pair exactly as stage 1 forms it.
+// in: 12 floats per item: the five scaled triangle values (16 b, 16 c, 16 Mc'/S), the five scaled ray values (P_b, P_c, -dir), the ray's
+// P_a (a half), 0.  One wave per item; out: 2 floats: the matrix instruction's result, and the same 16 products summed in double.
+__global__ void __launch_bounds__(64) k_selftest_cylm(const float* __restrict__ in, uint32_t n, float* __restrict__ out) {
+	const uint32_t i = blockIdx.x, lane = threadIdx.x, hh = lane >> 5;
+	if (i >= n) return;
+	const float* q = in + 12 * (size_t)i;
+	_Float16 th[5], tl[5], rh[5], rl[5];
+#pragma unroll
+	for (int k = 0; k < 5; ++k) { half_split(q[k], th[k], tl[k]); half_split(q[5 + k], rh[k], rl[k]); }
+	const _Float16 ah = to_half(q[10]), z = (_Float16)0.0f, one16 = (_Float16)16.0f;
+	const half8 a0 = { th[0], tl[0], th[0], th[1], tl[1], th[1], th[2], tl[2] }, a1 = { th[2], th[3], tl[3], th[3], th[4], tl[4], th[4], one16 };
+	const half8 b0 = { rh[0], rh[0], rl[0], rh[1], rh[1], rl[1], rh[2], rh[2] }, b1 = { rl[2], rh[3], rh[3], rl[3], rh[4], rh[4], rl[4], ah };
+	const half8 zero8 = { z, z, z, z, z, z, z, z };
+	const bool mine = (lane & 31u) == 0u;                       // row 0 / column 0 carry the item, everything else is zero
+	const half8 af = mine ? (hh ? a1 : a0) : zero8, bf = mine ? (hh ? b1 : b0) : zero8;
+	float16v c;
+#pragma unroll
+	for (int k = 0; k < 16; ++k) c[k] = 0.0f;
+	const float16v g = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, c, 0, 0, 0);
+	if (lane == 0) {
+		double sum = 0.0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) sum += (double)(float)a0[k] * (double)(float)b0[k] + (double)(float)a1[k] * (double)(float)b1[k];
+		out[2 * (size_t)i] = g[0];
+		out[2 * (size_t)i + 1] = (float)sum;
+	}
+}
+
 constexpr uint32_t kMCap = 512u;             // list entries per wave and pass (16 bits each: ray << 6 | group)
 
 // Closest hit for the ray of every lane.  Block-uniform call (barriers inside).
@@ -178,7 +217,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		const float Pa_ = cls == 0u ? Pw[0] : cls == 1u ? Pw[1] : Pw[2];
 		const float Pb_ = cls == 0u ? Pw[1] : cls == 1u ? Pw[2] : Pw[0], Pc_ = cls == 0u ? Pw[2] : cls == 1u ? Pw[0] : Pw[1];
 		// scale the ray by t so that its P_a is exactly a half
-		const _Float16 ah = (_Float16)Pa_;
+		const _Float16 ah = to_half(Pa_);
 		const float fa = (float)ah;
 		const bool big = fabsf(Pa_) >= 0x1p-10f;
 		const float t = big ? fa / Pa_ : 1.0f;
@@ -236,6 +275,17 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			for (int j = 0; j < 4; ++j) Hq[j] = cur[cylm_slot(tb * 8u + 2u * (uint32_t)j + hh, 7u)];
 			const float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[0], zero, 0, 0, 0);
 			const float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[1], zero, 0, 0, 0);
+#ifdef SP_DBG_PRINT
+			if (blockIdx.x == 0 && tid == 0)
+				printf("[cylm] gt %u cls %u tb %u S %g left %u | g0 %g %g %g %g | H %g %g %g %g | Dn %g Dqn %g | afr %g %g %g %g %g %g %g %g | bfr %g %g %g %g %g %g %g %g\n", gt, cls, tb, S, left,
+				       g0[0], g0[1], g0[2], g0[3], Hq[0].x, Hq[0].y, Hq[0].z, Hq[0].w, Dn[0], Dqn[0],
+				       (float)afr[0], (float)afr[1], (float)afr[2], (float)afr[3], (float)afr[4], (float)afr[5], (float)afr[6], (float)afr[7],
+				       (float)bfr[0][0], (float)bfr[0][1], (float)bfr[0][2], (float)bfr[0][3], (float)bfr[0][4], (float)bfr[0][5], (float)bfr[0][6], (float)bfr[0][7]);
+			if (blockIdx.x == 0 && tid == 32)
+				printf("[cylm h1] gt %u tb %u | afr %g %g %g %g %g %g %g %g | bfr %g %g %g %g %g %g %g %g\n", gt, tb,
+				       (float)afr[0], (float)afr[1], (float)afr[2], (float)afr[3], (float)afr[4], (float)afr[5], (float)afr[6], (float)afr[7],
+				       (float)bfr[0][0], (float)bfr[0][1], (float)bfr[0][2], (float)bfr[0][3], (float)bfr[0][4], (float)bfr[0][5], (float)bfr[0][6], (float)bfr[0][7]);
+#endif
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb) {
 				const float16v& g = rb == 0 ? g0 : g1;
@@ -251,6 +301,9 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		const uint32_t done = nblk * 4u;                              // bits appended; left-align
 #pragma unroll
 		for (int rb = 0; rb < 2; ++rb) word[rb] = done == 0u ? 0u : (word[rb] << (32u - done));
+#ifdef SP_DBG_ALLBITS
+		word[0] = word[1] = done == 0u ? 0u : (0xffffffffu << (32u - done));
+#endif
 		// the next tile streams in while the survivors are resolved
 		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, sm + ((gt + 1u) & 1u) * kMTileQ, tid, wbase);
 		// ---- stage 2: one list per wave; entry = (ray = donor lane) << 6 | group

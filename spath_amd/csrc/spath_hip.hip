@@ -892,8 +892,8 @@ int sphip_render(sphip_t* c, const float* rays, size_t w, size_t h, size_t n_sam
 
 int sphip_selftest_device(sphip_t* c, int what, const void* in, size_t n, void* out) {
 	if (!c) return SPHIP_E_INVALID;
-	static const size_t in_b[6] = { 4, 4, 20, 40, 60, 12 }, out_b[6] = { 8, 4, 16, 12, 4, 4 };
-	if (what < 0 || what > 5 || !in || !out || n == 0 || n > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad selftest arguments (what=%d n=%zu)", what, n);
+	static const size_t in_b[7] = { 4, 4, 20, 40, 60, 12, 48 }, out_b[7] = { 8, 4, 16, 12, 4, 4, 8 };
+	if (what < 0 || what > 6 || !in || !out || n == 0 || n > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad selftest arguments (what=%d n=%zu)", what, n);
 	sphip_ctx* k = c->kids.empty() ? c : c->kids[0];
 	HIP_TRY(c, hipSetDevice(k->device));
 	void *d_in = nullptr, *d_out = nullptr;
@@ -901,7 +901,8 @@ int sphip_selftest_device(sphip_t* c, int what, const void* in, size_t n, void* 
 	hipError_t e = hipMalloc(&d_out, n * out_b[what]);
 	if (e == hipSuccess) e = hipMemcpy(d_in, in, n * in_b[what], hipMemcpyHostToDevice);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(sp::k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k->own_stream, what, (const void*)d_in, (uint32_t)n, d_out);
+		if (what == 6) hipLaunchKernelGGL(sp::k_selftest_cylm, dim3((unsigned)n), dim3(64), 0, k->own_stream, (const float*)d_in, (uint32_t)n, (float*)d_out);
+		else hipLaunchKernelGGL(sp::k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k->own_stream, what, (const void*)d_in, (uint32_t)n, d_out);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(k->own_stream);
