@@ -182,7 +182,9 @@ int sphip_plan_shard(size_t width, size_t height, int n_devices, size_t tile_row
  *        2  philox_uniforms (replaces frand.h:53-63)               in u32[5n] seed lo, hi, pixel, sample, depth   out f64[2n]
  *        3  rand_unit_vec  (geom.h:164-177, the two draws given)   in f64[5n] n.xyz, r1, r2           out f32[3n]
  *        4  ray_tri_strict (geom.h:197-222)                        in f32[15n] pos dir v0 v1 v2       out f32[n] distance or -1
- *        5  vec3_rgba      (scene.h:32-39)                         in f32[3n]                         out u32[n] */
+ *        5  vec3_rgba      (scene.h:32-39)                         in f32[3n]                         out u32[n]
+ *        6  the f16 matrix-pipe side product of sp_cylm_scan.h      in f32[12n] 5 triangle values, 5 ray values, P_a (a half), 0
+ *                                                                  out f32[2n] the instruction's result, the same 16 products summed in double */
 int sphip_selftest_device(sphip_t* ctx, int what, const void* in, size_t n, void* out);
 
 /* Blocks until the last render on this context has finished, then reports its figures. */

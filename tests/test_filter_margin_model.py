@@ -201,3 +201,80 @@ def test_cylinder_filter_is_conservative_and_implies_the_slab_reject():
     slack = (np.abs(gmu) - np.abs(tu))[reject] / (U * mag[reject])
     assert slack.min() > 2 * 44.0, slack.min()                  # needed: 88u; the margin leaves >= 256u/sqrt(3) ~ 148u even for the scaled w
     print(f"cylinder filter: rejects {reject.mean():.3f}, accepted by the strict test {acc.mean():.3f}; smallest slab slack among its rejections {slack.min():.0f} u (needed 88 u)")
+
+
+def _half_split(v):
+    hi = v.astype(np.float16)
+    lo = (v.astype(F) - hi.astype(F)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def test_matrix_pipe_filter_is_conservative_and_implies_the_slab_reject():
+    """Third-generation stage 1 (sp_cylm_scan.h): the same x = |gm'| - H*D with gm' evaluated as the matrix instruction does --
+    every operand split into two halves (v = hi + lo), three half products per term, P_a as one half after scaling the ray by
+    t = half(P_a)/P_a, everything scaled by exact powers of two (S for lengths, s_d for the direction), accumulated in f32
+    (modelled: the 16 products summed in double, then rounded once; the device figure, 2^-21.5 of the sum of the |terms|,
+    is measured by tests/test_hip_device_math.py).  Checks as for the cylinder filter: never rejects what the strict
+    evaluation accepts; every rejection has the slab slack the proof needs."""
+    rng = np.random.default_rng(79)
+    n = 400_000
+    pos, d, v0, v1, v2 = make_pairs(rng, n)
+    d = (d * np.where(rng.random((n, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-3, 3, (n, 1)))).astype(F)
+    acc, a_f, sh, vq, e1, e2 = strict(pos, d, v0, v1, v2)
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    cd = e2d - e1d
+    l1, l2, lc = (e1d ** 2).sum(1), (e2d ** 2).sum(1), (cd ** 2).sum(1)
+    use_u, use_v = (l2 >= l1) & (l2 >= lc), ~((l2 >= l1) & (l2 >= lc)) & (l1 >= lc)
+    w = np.where(use_u[:, None], e2d, np.where(use_v[:, None], e1d, cd))
+    p0 = np.where(use_u[:, None] | use_v[:, None], v0, v1)
+    p1 = np.where(use_u[:, None], v1, np.where(use_v[:, None], v2, v0))
+    a, b, c, beta, gamma, mc, H = cyl_records(w, p0, p1)
+    idx = np.arange(n)
+    P = cross(pos, d)
+    rv = F(max(np.abs(v).sum(axis=1).max() for v in (v0, v1, v2)))
+    S = F(2.0 ** (np.floor(np.log2(float(rv))) + 2))                 # the power of two in (2 Rv, 4 Rv]
+    assert 2 * rv <= S <= 4 * rv * (1 + 1e-6)
+    dmax = np.abs(d).max(axis=1)
+    s_d = (2.0 ** -np.floor(np.log2(dmax.astype(np.float64)))).astype(F)     # dmax * s_d in [1, 2)
+    kP, kN, kC = (s_d * F(16.0 / S)).astype(F), (F(16.0) * s_d).astype(F), (s_d * F(256.0 / S)).astype(F)
+    D = (np.sqrt(((d * d)[:, 0] + (d * d)[:, 1]) + (d * d)[:, 2]).astype(F) * F(1.0 + 2.0 ** -21)).astype(F)
+    d1 = np.abs(d).sum(axis=1).astype(np.float64)
+    p1n = np.abs(pos).sum(axis=1).astype(np.float64)
+    Dq = np.maximum((F(2.0 ** -16 * 1.01) * (d1 * (p1n + 2.0 * float(rv))).astype(F) * F(1.0 + 2.0 ** -20)).astype(F), F(1e-37))
+    Pa_, Pb_, Pc_ = (P[idx, a] * kP).astype(F), (P[idx, b] * kP).astype(F), (P[idx, c] * kP).astype(F)
+    ah = Pa_.astype(np.float16).astype(F)
+    big = np.abs(Pa_) >= F(2.0 ** -10)
+    with np.errstate(all="ignore"):
+        t = np.where(big, (ah.astype(np.float64) / Pa_.astype(np.float64)).astype(F), F(1.0)).astype(F)
+    extra = np.where(big, F(0.0), (np.abs(Pa_ - ah) * F(16.0)).astype(F)).astype(F)
+    ray_vals = [(Pb_ * t).astype(F), (Pc_ * t).astype(F)] + [((-d[:, k]) * kN * t).astype(F) for k in range(3)]
+    tri_vals = [(F(16.0) * beta).astype(F), (F(16.0) * gamma).astype(F)] + [(mc[:, k] * F(16.0 / S)).astype(F) for k in range(3)]
+    g = 16.0 * ah.astype(np.float64)
+    for rvl, tvl in zip(ray_vals, tri_vals):
+        rh, rl = _half_split(rvl)
+        th, tl = _half_split(tvl)
+        g = g + th * rh + tl * rh + th * rl
+    g = g.astype(F)
+    Hh = (H * F(256.0 / S)).astype(F)
+    Dt = (D * s_d * t).astype(F)
+    Dqt = (((Dq * kC) * t + extra) * F(1.0 + 2.0 ** -20)).astype(F)
+    x = fma(-Hh, Dt, np.abs(g))
+    in_range = (p1n + 2.0 * float(rv)) <= 512.0 * float(S)
+    reject = ~((x - Dqt) < 0) & np.isfinite(x) & in_range
+    assert not (reject & acc).any(), int((reject & acc).sum())
+    assert 0.01 < reject.mean() < 0.9
+    # the f32 cylinder filter rejects (nearly) the same pairs: the halves cost no selectivity
+    gm = fma(beta, P[idx, b], P[idx, a]); gm = fma(gamma, P[idx, c], gm)
+    for k in range(3): gm = fma(-d[:, k], mc[:, k], gm)
+    rej32 = ~((fma(-H, D, np.abs(gm)) - Dq) < 0)
+    assert abs(int(reject.sum()) - int((rej32 & in_range).sum())) <= 1e-3 * n
+    wn = w / np.linalg.norm(w, axis=1, keepdims=True)
+    posd, dd = pos.astype(np.float64), d.astype(np.float64)
+    Pd = np.cross(posd, dd)
+    gmu = (wn * Pd).sum(1) - (dd * np.cross(wn, 0.5 * (p0.astype(np.float64) + p1.astype(np.float64)))).sum(1)
+    tu = (dd * np.cross(wn, 0.5 * (p1.astype(np.float64) - p0.astype(np.float64)))).sum(1)
+    mag = np.linalg.norm(dd, axis=1) * (np.linalg.norm(posd, axis=1) + np.linalg.norm(v0.astype(np.float64), axis=1)
+                                         + np.linalg.norm(v1.astype(np.float64), axis=1) + np.linalg.norm(v2.astype(np.float64), axis=1))
+    slack = (np.abs(gmu) - np.abs(tu))[reject] / (U * mag[reject])
+    assert slack.min() > 2 * 44.0, slack.min()
+    print(f"matrix-pipe filter: rejects {reject.mean():.3f} (f32 cylinder filter: {rej32.mean():.3f}); smallest slab slack among its rejections {slack.min():.0f} u (needed 88 u)")

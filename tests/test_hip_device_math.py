@@ -137,3 +137,33 @@ def test_vec3_rgba_every_quantisation_boundary(hip, O):
     assert np.array_equal(hip.selftest(5, v, v.shape[0]), O.device_math(5, v, v.shape[0]))
     big = rng.uniform(-0.1, 1.1, (1 << 20, 3)).astype(F)
     assert np.array_equal(hip.selftest(5, big, big.shape[0]), O.device_math(5, big, big.shape[0]))
+
+
+def test_matrix_pipe_side_product_accuracy(hip):
+    """sp_cylm_scan.h stage 1: the side product of one (triangle, ray) pair through v_mfma_f32_32x32x16_f16 -- operands split
+    into two halves each, three half products per term, 16 products accumulated by the instruction -- against the same 16
+    products summed in double.  The conservativeness argument allows 16u of the sum of the |terms| for the
+    accumulation (u = 2^-24); measured here: <= 2^-21 (8u), values over the whole range the scaling produces."""
+    f16 = np.float16
+    rng = np.random.default_rng(6)
+    n = 300000
+    q = np.zeros((n, 12), dtype=np.float32)
+    q[:, :5] = rng.uniform(-16, 16, (n, 5)) * 10.0 ** rng.uniform(-4, 0, (n, 5))            # 16 b, 16 c, 16 Mc'/S
+    q[:, 5:10] = rng.uniform(-32, 32, (n, 5)) * 10.0 ** rng.uniform(-4, 0, (n, 5))          # scaled P_b, P_c, -dir
+    q[: n // 8, 5:7] *= 512.0                                                                 # rays far from the origin: up to 2^14
+    q[:, 10] = f16(rng.uniform(-30, 30, n) * 10.0 ** rng.uniform(-3, 0, n)).astype(np.float32)
+    got = hip.selftest(6, q, n).reshape(-1, 2).astype(np.float64)
+    # host reference of the same sum (halves by numpy's round-to-nearest-even float16)
+    ref = 16.0 * q[:, 10].astype(np.float64)
+    for k in range(5):
+        th = q[:, k].astype(f16); tl = (q[:, k] - th.astype(np.float32)).astype(f16)
+        rh = q[:, 5 + k].astype(f16); rl = (q[:, 5 + k] - rh.astype(np.float32)).astype(f16)
+        ref += th.astype(np.float64) * rh.astype(np.float64) + tl.astype(np.float64) * rh.astype(np.float64) + th.astype(np.float64) * rl.astype(np.float64)
+    mag = 16.0 * np.abs(q[:, 10].astype(np.float64)) + (np.abs(q[:, :5].astype(np.float64)) * np.abs(q[:, 5:10].astype(np.float64))).sum(1)
+    assert (np.abs(got[:, 1] - ref) <= 2.0 ** -23 * mag + 1e-30).all()                        # the device's own double sum = the host's (its float rounding aside)
+    err = np.abs(got[:, 0] - ref) / np.maximum(mag, 1e-30)
+    assert err.max() <= 2.0 ** -21, (err.max(), np.log2(err.max()))
+    # and the splitting itself: the three half products reproduce the float product to 3 x 2^-22 (+ the subnormal floor of the halves)
+    prod = 16.0 * q[:, 10].astype(np.float64) + (q[:, :5].astype(np.float64) * q[:, 5:10].astype(np.float64)).sum(1)
+    floor = 2.0 ** -24 * (np.abs(q[:, :5]).sum(1) + np.abs(q[:, 5:10]).sum(1))
+    assert (np.abs(ref - prod) <= 3.0 * 2.0 ** -22 * mag + floor).all()

@@ -197,3 +197,36 @@ def test_rays_in_the_plane_of_far_triangles_noise_accepts(hip, O):
     sub = np.flatnonzero(own)[:3000]
     oi, od = O.closest_hits(rays[sub], t)
     assert np.array_equal(oi, res[2][0][sub]) and np.array_equal(od.view(np.uint32), res[2][1][sub])
+
+
+def test_aimed_rays_at_small_triangles_in_small_scenes():
+    """Rays aimed at points of tiny triangles from metres away, unnormalised directions, a few triangles per scene: the regime in
+    which a one-ulp error of a half operand of the matrix-pipe stage 1 (rpl_cylm) rejected true hits (found by tools/soak.py: the
+    fragment value and its remainder had come from two float->half conversions that round a near-tie differently).  Every
+    two-stage scan against the exact-only scan, (index, distance bits), with random idx_source."""
+    rng = np.random.default_rng(20260105)
+    hip = capi.Context(0)
+    two_stage = [v for v in VARIANTS if v >= 3]
+    nr = 20000
+    for it in range(160):
+        n = int(rng.integers(1, 40))
+        scale = 10.0 ** rng.uniform(-2.5, 0.5, (n, 1)); ctr = rng.uniform(-2, 2, (n, 3)) * [1, 0.6, 1]
+        t = np.zeros((n, 12), dtype=np.float32)
+        for k in range(3): t[:, 3 * k:3 * k + 3] = ctr + rng.normal(size=(n, 3)) * scale
+        t = scene.flat_normals(t); t[:, 9:12] = np.nan_to_num(t[:, 9:12])
+        m = np.full((n, 6), 0.5, dtype=np.float32)
+        hip.set_scene(t, m)
+        hr = np.concatenate([rng.uniform(-3, 3, (nr, 3)), rng.normal(size=(nr, 3))], axis=1).astype(np.float32)
+        v = t[:, :9].reshape(-1, 3, 3); k = rng.integers(0, n, nr * 3 // 4); bw = rng.dirichlet([0.3, 0.3, 0.3], nr * 3 // 4)
+        hr[: nr * 3 // 4, 3:] = (v[k] * bw[:, :, None]).sum(1) - hr[: nr * 3 // 4, :3]
+        src = rng.integers(-1, n, nr).astype(np.int32)
+        d_r, d_s = torch.from_numpy(hr).cuda(), torch.from_numpy(src).cuda()
+        oi = torch.zeros(nr, dtype=torch.int32, device="cuda"); od = torch.zeros(nr, dtype=torch.float32, device="cuda")
+        res = {}
+        for var in [2] + two_stage:
+            hip.closest_hit_device(d_r.data_ptr(), nr, oi.data_ptr(), od.data_ptr(), d_src_idx=d_s.data_ptr(), flags=var); torch.cuda.synchronize()
+            res[var] = (oi.cpu().numpy().copy(), od.cpu().numpy().view(np.uint32).copy())
+        assert (res[2][0] >= 0).mean() > 0.3
+        for var in two_stage:
+            assert np.array_equal(res[var][0], res[2][0]) and np.array_equal(res[var][1], res[2][1]), (it, n, var)
+    hip.close()
