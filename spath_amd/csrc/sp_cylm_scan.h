@@ -246,6 +246,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 	};
 	build_b(0u);
 
+
 	const uint32_t total_tiles = cs.hdr[6];
 	uint32_t cls = 0;
 #ifdef SP_EXP_NO_STAGE2
@@ -345,8 +346,8 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				const int L = (int)(entry >> 6);
 				const uint32_t grp = entry & 63u;
 				const float ox = __shfl(s.o[0].x, L, 64), oy = __shfl(s.o[0].y, L, 64), oz = __shfl(s.o[0].z, L, 64);
-				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
 				const int src = __shfl(s.src[0], L, 64);
+				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
 				const float Pa = __shfl(f.Pa[0], L, 64), Pb = __shfl(f.Pb[0], L, 64), Pc = __shfl(f.Pc[0], L, 64);
 				const float D = __shfl(f.D[0], L, 64), Dq = __shfl(f.Dq[0], L, 64);
 				// the f32 cylinder test of sp_cyl_scan.h on the group's four records: which of them survive
