@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (~2.5 PF)
 VALU_PEAK_TINSTR = 256 * 4 * 32 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.64 T lane-instructions/s
 BYTES_PER_TEST = 48          # sizeof(geom::triangle)
 FLOPS_PER_TEST = 52
@@ -408,7 +409,8 @@ def main():
             "kernel_ms_per_rank": {"min": round(kern_ms_min, 3), "max": round(kern_ms_max, 3)},
             "worst_case_untimed": worst,
             "roofline": {
-                # the binding roof: FP32 vector instruction issue (no MFMA on this path; HBM is idle, see `traffic`)
+                # the binding roof: FP32 vector instruction issue (HBM is idle, see `traffic`; the f16 matrix pipe carries stage 1's side
+                # products in rpl_cylm but is the less loaded of the two pipes, see `mfma`)
                 "bound": "valu",
                 "achieved": round(valu_achieved, 3) if valu_achieved else None,
                 "peak": round(VALU_PEAK_TINSTR, 3),
@@ -432,6 +434,11 @@ def main():
                                   "note": "effective (logical-stream) bandwidth of rank 0's launch; exceeds the HBM peak because a record fetched "
                                           "into LDS serves every ray of the workgroup and the stream lives in L2; HBM really moved `traffic` bytes"},
                 "algorithmic_flop_frac": round(my_scans * NT * FLOPS_PER_TEST / avg_kernel_s / (FP32_PEAK_TFLOPS * 1e12), 4),
+                # rpl_cylm: one v_mfma_f32_32x32x16_f16 (32768 flop) per 32 x 32 ray-triangle tests = 32 executed f16 flop per test
+                "mfma": ({"achieved": round(tests_per_s * 32.0 / 1e12, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(tests_per_s * 32.0 / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                          "note": "executed flop of the matrix instruction (K = 16: 15 half products + 1 for P_a per test), dense f16 peak"}
+                         if kname == "rpl_cylm" else None),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
