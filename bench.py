@@ -386,7 +386,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -37,7 +37,7 @@ def test_bench_line_small_workload():
     assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3
     assert r["filter"]["queue_overflows"] == 0 and d["rccl_ranks"] == 1
     assert d["worst_case_untimed"]["Mray_per_s"] > 0
-    assert abs(d["value"] - d["nominal_rays_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert abs(d["value"] - d["nominal_rays_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3 + 1e-4 / d["ms_per_step"]    # (rounding of the printed ms)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mray/s" and "sample" in c
     assert d["scans_per_step"] <= d["nominal_rays_per_step"]
