@@ -12,7 +12,7 @@ dev = torch.device("cuda")
 d_t, d_m, d_r = torch.from_numpy(t).to(dev), torch.from_numpy(m).to(dev), torch.from_numpy(rays).to(dev)
 ctx.set_scene_device(d_t.data_ptr(), d_m.data_ptr(), 10000, 0)
 res = {}
-for name, var in (("auto (rpl_cylw4s)", 0), ("rpl_cyl4s (per-lane stage 2)", 13), ("rpl_filter2s", 6), ("rpl_lds (exact only)", 2)):
+for name, var in (("auto (rpl_cylm)", 0), ("rpl_cylw4s (f32 stage 1)", 15), ("rpl_cyl4s (per-lane stage 2)", 13), ("rpl_filter2s", 6), ("rpl_lds (exact only)", 2)):
     img = torch.zeros(w * h, 4, dtype=torch.uint8, device=dev); acc = torch.zeros(w * h, 3, dtype=torch.float32, device=dev)
     ctx.render_device(d_r.data_ptr(), w * h, spp, img.data_ptr(), seed=1, flags=var, d_out_accum=acc.data_ptr())
     torch.cuda.synchronize(); st = ctx.stats()
