@@ -45,6 +45,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define SP_CYLM_TILE 256
 #endif
 
+
 constexpr uint32_t kMTile = SP_CYLM_TILE;        // triangles per tile
 constexpr uint32_t kMGroups = kMTile / 4u;        // 48
 constexpr uint32_t kMBlocks = kMTile / 32u;       // 6 fragments
