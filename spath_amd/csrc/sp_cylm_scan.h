@@ -22,16 +22,17 @@
 // further than 512 S from the origin, or outside the guards of cyl_setup, has its filter off (everything survives) as before.
 //
 // Error budget (u = 2^-24, X = |dir|(|pos| + 2Rv) sqrt(3) bounding the sum of the |terms| as in DESIGN.md 4.2): splitting
-// 3 x 2^-22 = 12u per product, the accumulation of 16 terms in f32 <= 16u, the scaling by t 2u, against the 7u of the VALU chain
-// they replace; needed by the proof 152u + (30u - 7u) sqrt(3) = 192u of the 256u the margin provides.
+// 3 x 2^-22 = 12u per product, the accumulation of 16 terms in f32 <= 16u (measured on the device: 2^-21.5 = 6u,
+// tests/test_hip_device_math.py), the scaling by t 2u, against the 7u of the VALU chain they replace; needed by the proof 152u + (30u - 7u) sqrt(3) = 192u of the 256u the margin provides.
 // Absolute floors (subnormal lo parts, 2^-25 per value) are 2^-13 of that after the scaling by 16.
 //
 // Work shape: ONE ray per lane (the matrix instruction reads a whole 32-triangle fragment with one 16-B LDS read per lane, so
 // nothing is gained from several rays per lane).  A wave owns 64 rays = two column blocks; lane l holds, of ray block rb, column
 // l & 31 -- its own ray when (l >> 5) == rb, its partner's otherwise -- and the rows (triangles) 8j + 4(l >> 5) + i of a
 // fragment: the four i of a j are one GROUP of sp_cyl_scan.h, so the sign bits are per (ray, group) exactly as there.
-// Tile: 192 triangles = 12 KB: [8 chunks][48 groups] float4 as in sp_cyl_scan.h (chunk 7 = the four H^ of the group) followed by
-// the A fragments [6 blocks of 32][64 lanes] x 16 B.
+// Tile: 256 triangles = 16 KB: [8 chunks][64 groups] float4 as in sp_cyl_scan.h (chunk 7 = the four H^ of the group) followed by
+// the A fragments [8 blocks of 32][64 lanes] x 16 B; 8 fragments x 4 group bits = one 32-bit word per ray block (128 / 192-triangle
+// tiles: -15 % / -4 %).  Build hooks for experiments: SP_EXP_NO_STAGE2 (timing only), SP_DBG_ALLBITS, SP_DBG_PRINT, SP_CYLM_UNPINNED.
 #pragma once
 
 #include "sp_cyl_scan.h"
@@ -45,12 +46,11 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define SP_CYLM_TILE 256
 #endif
 
-
 constexpr uint32_t kMTile = SP_CYLM_TILE;        // triangles per tile
-constexpr uint32_t kMGroups = kMTile / 4u;        // 48
-constexpr uint32_t kMBlocks = kMTile / 32u;       // 6 fragments
-constexpr uint32_t kMRecQ = kMGroups * 8u;        // 384 float4: the f32 part
-constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 768 float4 = 12 KB
+constexpr uint32_t kMGroups = kMTile / 4u;        // 64 groups of four
+constexpr uint32_t kMBlocks = kMTile / 32u;       // 8 fragments
+constexpr uint32_t kMRecQ = kMGroups * 8u;        // 512 float4: the f32 part
+constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 1024 float4 = 16 KB
 static_assert(kMTileQ % 256u == 0u, "whole workgroup LDS-DMA passes");
 static_assert(kMGroups <= 64u && kMBlocks * 4u <= 32u, "6-bit group index in a list entry; one 32-bit word of group bits per ray block");
 SP_DEV constexpr uint32_t cylm_slot(uint32_t group, uint32_t chunk) { return chunk * kMGroups + group; }
