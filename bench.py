@@ -15,15 +15,17 @@ scaling; spath_amd/dist.py); each step ends with one RCCL gather of the RGBA8 ti
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus `roofline` and
 `cpu_baseline`:
-  roofline            the BINDING roof of the dominant kernel: FP32 vector (VALU) instruction issue.
+  roofline            the most loaded pipe of the dominant kernel: FP32 vector (VALU) instruction issue.
                       achieved = executed lane-instructions per second = ray-triangle tests/s x lane-instructions
                       per test, the latter from a committed rocprofv3 PMC pass of this very command
                       (profiles/valu_issue.json <- tools/valu_issue_from_pmc.py <- SQ_INSTS_VALU);
                       peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md).  frac <= 1.
+  roofline.mfma       the default scan (rpl_cylm) evaluates stage 1's side products on the f16 matrix pipe: executed matrix
+                      flop/s (32 per test) against the 2.5 PFLOP/s dense f16 peak -- the less loaded of the two pipes.
   roofline.hbm_effective   the accounting SURVEY.md 8(d) / the north_star name: scans x n_tris x 48 B
                       (sizeof(geom::triangle), what the reference's scan reads per ray) / kernel time against the
                       8 TB/s HBM peak.  It is an EFFECTIVE bandwidth and exceeds 1: every triangle fetched into LDS
-                      serves 1024 rays, the 320 KB record stream lives in L2; `traffic` is what HBM really moved.
+                      serves the 256 rays of a workgroup, the 640 KB record stream lives in L2; `traffic` is what HBM really moved.
 Kernel time = HIP events on the launch stream around every step's kernels.
 """
 from __future__ import annotations
