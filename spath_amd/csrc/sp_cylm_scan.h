@@ -199,10 +199,15 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 	const float on = fabsf(s.o[0].x) + fabsf(s.o[0].y) + fabsf(s.o[0].z);
 	const float dmax = fmaxf(adx, fmaxf(ady, adz));
 	// cyl_setup's verdict (filter on: finite margin) plus the range of the halves; off: zero operands and a margin of +inf
-	const bool on_m = (f.Dq[0] < __builtin_inff()) && (f.Dq[0] > 0.0f) && (S > 0.0f) && (on + 2.0f * rv <= 512.0f * S);
+	const bool on0 = (f.Dq[0] < __builtin_inff()) && (f.Dq[0] > 0.0f) && (S > 0.0f) && (on + 2.0f * rv <= 512.0f * S);
 	const uint32_t ed = (__float_as_uint(dmax) >> 23) & 255u;
-	const float s_d = on_m ? __uint_as_float((254u - ed) << 23) : 0.0f;                 // 2^-(e-127): dmax * s_d in [1, 2)
-	const float kP = on_m ? s_d * (16.0f / S) : 0.0f, kN = 16.0f * s_d, kC = on_m ? s_d * (256.0f / S) : 0.0f;
+	const float sd0 = on0 ? __uint_as_float((254u - ed) << 23) : 0.0f;                  // 2^-(e-127): dmax * s_d in [1, 2)
+	// the scale factors themselves must stay in range: a 1e-30 scene traversed with 1e-18 directions would make them overflow
+	// (cyl_setup's guards bound |dir| and |dir|(|pos| + 2Rv) from above, not Rv from below against |dir|)
+	const float kP0 = on0 ? sd0 * (16.0f / S) : 0.0f, kC0 = on0 ? sd0 * (256.0f / S) : 0.0f;
+	const bool on_m = on0 && (kC0 < 1e30f) && (kP0 > 1e-30f);
+	const float s_d = on_m ? sd0 : 0.0f;
+	const float kP = on_m ? kP0 : 0.0f, kN = 16.0f * s_d, kC = on_m ? kC0 : 0.0f;
 	const float Dh = on_m ? f.D[0] * s_d : 1.0f;
 	// inactive lane: Dq = -inf (rejected); filter off: +inf; else scaled (exact)
 	const float Dqh = on_m ? f.Dq[0] * kC : (s.act[0] ? __builtin_inff() : -__builtin_inff());

@@ -230,3 +230,28 @@ def test_aimed_rays_at_small_triangles_in_small_scenes():
         for var in two_stage:
             assert np.array_equal(res[var][0], res[2][0]) and np.array_equal(res[var][1], res[2][1]), (it, n, var)
     hip.close()
+
+
+def test_extreme_scale_combinations_of_scene_and_direction(hip, O):
+    """Scene size and direction length at opposite ends of their ranges (the matrix-pipe stage 1 scales both sides by powers of two;
+    the products of the scale factors must not leave the float range), cameras hundreds of scene radii away (its halves would
+    overflow: filter off for those rays), and the plain cases in between: every scan against the oracle, bit for bit."""
+    rng = np.random.default_rng(77)
+    t0, _ = scene.closed_room(300)
+    n = 6000
+    for scene_scale, dir_scale, far in ((1e-28, 1e-17, 1.0), (1e-28, 1e17, 1.0), (1e25, 1e-17, 1.0), (1e25, 1e10, 1.0), (1e-12, 1e-6, 1.0),
+                                       (1.0, 1.0, 700.0), (1.0, 1e-10, 3000.0), (1e-3, 1e3, 1.0e5), (1.0, 1.0, 1.0)):
+        t = t0.copy()
+        t[:, :9] *= np.float32(scene_scale)
+        v = t[:, :9].reshape(-1, 3, 3)
+        o = rng.uniform(-1.4, 1.4, (n, 3)) * [1, 0.5, 1] * scene_scale * far
+        k = rng.integers(0, t.shape[0], n); bw = rng.dirichlet([0.5, 0.5, 0.5], n)
+        d = (v[k] * bw[:, :, None]).sum(1).astype(np.float64) - o                   # aimed at the triangles
+        d[n // 2:] = rng.normal(size=(n - n // 2, 3))                               # and random directions
+        d = d / np.linalg.norm(d, axis=1, keepdims=True) * dir_scale
+        rays = np.concatenate([o, d], axis=1).astype(np.float32)
+        with np.errstate(all="ignore"):
+            hip.set_scene(t, np.full((t.shape[0], 6), 0.5, dtype=np.float32))
+            idx = _hits(hip, O, t, rays, (scene_scale, dir_scale, far))
+        if 1e-4 < scene_scale < 1e3 and far <= 1.0:                # (elsewhere the determinant falls under the epsilon of geom.h:204 or overflows: no hits at all)
+            assert (idx >= 0).mean() > 0.3, (scene_scale, dir_scale, far)
