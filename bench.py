@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (~2.5 PF)
+VALU_MEASURED_FMAC_TINSTR = 56.7   # measured on MI355X, 4 waves/SIMD, independent v_fmac_f32 chains (profiles/r01_valu_microbench_extended.log)
 VALU_PEAK_TINSTR = 256 * 4 * 32 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.64 T lane-instructions/s
 BYTES_PER_TEST = 48          # sizeof(geom::triangle)
 FLOPS_PER_TEST = 52
@@ -425,6 +426,10 @@ def main():
                 "lane_instr_per_test": lane_instr,
                 "lane_instr_source": vi.get("source", "no PMC pass committed for this configuration and kernel: valu fraction unavailable"),
                 "peak_definition": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md); one wave64 VALU instruction = 2 issue cycles",
+                # what a pure stream of independent v_fmac_f32 issues on this chip at the kernel's 4 waves per SIMD (tools/valu_bench.hip,
+                # profiles/r01_valu_microbench_extended.log: 56.7 T lane-instr/s; v_fma_f32 50-55, three-source min/med ops 31.5)
+                "measured_fmac_issue_rate": VALU_MEASURED_FMAC_TINSTR,
+                "frac_of_measured_fmac_rate": round(valu_achieved / VALU_MEASURED_FMAC_TINSTR, 4) if valu_achieved else None,
                 "sclk_observed_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
                 "frac_at_observed_sclk": round(valu_achieved / (256 * 4 * 32 * sclk_mhz * 1e6 / 1e12), 4) if (valu_achieved and sclk_mhz) else None,
                 "filter": {"pairs_surviving_stage1": fs.get("survivor_frac"), "stage2_rounds_per_tile": fs.get("rounds_per_tile"),

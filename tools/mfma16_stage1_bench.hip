@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256, 4) k_mfma(const h8* __restrict__ afrag_g,
 
 // ---- mode 2: ONE MFMA per 32 x 32 pairs: the 15 cross products fill K = 16, P_a enters through the accumulator input (C = P_a of the
 // lane's column ray in all 16 registers).  A fragments [tb][lane] 16 B, H [tb][h][16] floats
+template <int PART>
 __global__ void __launch_bounds__(256, 4) k_mfma1(const h8* __restrict__ afrag_g, const float* __restrict__ h_g, const float* __restrict__ rays, int iters, float eps, unsigned long long* out) {
 	__shared__ h8 sa[(kTile / 32) * 64];
 	__shared__ float sh[(kTile / 32) * 2 * 16];
@@ -191,8 +192,20 @@ __global__ void __launch_bounds__(256, 4) k_mfma1(const h8* __restrict__ afrag_g
 			const float4* hp = (const float4*)(sh + (tb * 2 + hh) * 16);
 			const float4 H0 = hp[0], H1 = hp[1], H2 = hp[2], H3 = hp[3];
 			f16v acc[2];
-			acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bfr[0], cin[0], 0, 0, 0);
-			acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bfr[1], cin[1], 0, 0, 0);
+			if (PART != 2) {
+				acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bfr[0], cin[0], 0, 0, 0);
+				acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bfr[1], cin[1], 0, 0, 0);
+			} else {                                                  // VALU only: something that depends on the loads, no matrix instruction
+#pragma unroll
+				for (int i = 0; i < 16; ++i) { acc[0][i] = cin[0][i] + H0.x * (float)i; acc[1][i] = cin[1][i] + H1.y * (float)i; }
+			}
+			if (PART == 1) {                                          // MFMA only: one cheap use of every result
+				uint32_t x0 = 0, x1 = 0;
+#pragma unroll
+				for (int i = 0; i < 16; ++i) { x0 |= __float_as_uint(acc[0][i]); x1 |= __float_as_uint(acc[1][i]); }
+				w[0] ^= x0 ^ __float_as_uint(H0.x + H1.x + H2.x + H3.x); w[1] ^= x1;
+				continue;
+			}
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb) {
 				const float Dr = Dn[rb] + bump, Dqr = Dqn[rb];
@@ -266,18 +279,20 @@ int main(int argc, char** argv) {
 	CHECK(hipMemcpy(d_t0, tile0.data(), tile0.size() * 16, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_a, afrag.data(), afrag.size() * 2, hipMemcpyHostToDevice));
 	CHECK(hipMemcpy(d_h, hfrag.data(), hfrag.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_r, rays.data(), rays.size() * 4, hipMemcpyHostToDevice));
 	hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-	for (int mode = 0; mode < 3; ++mode) {
+	for (int mode = 0; mode < 5; ++mode) {
 		for (int rep = 0; rep < 3; ++rep) {
 			CHECK(hipMemset(d_o, 0, 16));
 			CHECK(hipEventRecord(e0));
 			if (mode == 0) hipLaunchKernelGGL(k_valu, dim3(blocks), dim3(256), 0, 0, d_t0, d_r, iters, 0.0f, d_o);
 			else if (mode == 1) hipLaunchKernelGGL(k_mfma, dim3(blocks * 4), dim3(256), 0, 0, d_a, d_h, d_r, iters, 0.0f, d_o);
-			else           hipLaunchKernelGGL(k_mfma1, dim3(blocks * 4), dim3(256), 0, 0, d_a1, d_h, d_r, iters, 0.0f, d_o);
+			else if (mode == 2) hipLaunchKernelGGL(k_mfma1<0>, dim3(blocks * 4), dim3(256), 0, 0, d_a1, d_h, d_r, iters, 0.0f, d_o);
+			else if (mode == 3) hipLaunchKernelGGL(k_mfma1<1>, dim3(blocks * 4), dim3(256), 0, 0, d_a1, d_h, d_r, iters, 0.0f, d_o);
+			else           hipLaunchKernelGGL(k_mfma1<2>, dim3(blocks * 4), dim3(256), 0, 0, d_a1, d_h, d_r, iters, 0.0f, d_o);
 			CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
 			float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
 			unsigned long long cnt; CHECK(hipMemcpy(&cnt, d_o, 8, hipMemcpyDeviceToHost));
 			const double pairs = (double)n_rays * kTile * iters;
-			printf("mode %d (%s): %.2f ms, %.2f T pairs/s, popcount checksum %llu\n", mode, mode == 2 ? "1 MFMA 32x32x16 f16 (C = P_a) + 32 VALU per 1024 pairs, 1 ray/lane" : mode ? "2 MFMA 32x32x16 f16 + 32 VALU per 1024 pairs, 1 ray/lane" : "VALU production form, 4 rays/lane", ms, pairs / ms / 1e9, cnt);
+			printf("mode %d (%s): %.2f ms, %.2f T pairs/s, popcount checksum %llu\n", mode, mode == 4 ? "as mode 2 WITHOUT the matrix instructions (16 adds instead)" : mode == 3 ? "as mode 2 WITHOUT the VALU post-processing (16 ors instead)" : mode == 2 ? "1 MFMA 32x32x16 f16 (C = P_a) + 32 VALU per 1024 pairs, 1 ray/lane" : mode ? "2 MFMA 32x32x16 f16 + 32 VALU per 1024 pairs, 1 ray/lane" : "VALU production form, 4 rays/lane", ms, pairs / ms / 1e9, cnt);
 		}
 	}
 	return 0;
