@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SPHIP_ABI_VERSION 2
+#define SPHIP_ABI_VERSION 3
 
 typedef struct sphip_ctx sphip_t;
 
@@ -121,6 +121,9 @@ const char* sphip_last_error(const sphip_t* ctx);   /* ctx may be NULL: error of
 const char* sphip_description(const sphip_t* ctx);  /* renderer::get_description  src/renderer.h:26 */
 int  sphip_abi_version(void);
 const char* sphip_kernel_name(int variant);         /* NULL when the variant does not exist */
+int  sphip_kernel_available(int variant);           /* 1 when this build of the library carries the variant (the shipped build: the
+                                                       default scan, the exact-only scans, one f32 filter scan for A/B runs and the
+                                                       opt-in BVH; -DSP_ALL_VARIANTS builds: every generation), else 0 */
 
 /* ---- host-pointer path: exactly what renderer::render / render_flat receive
  * (src/renderer.h:31-32): borrowed host arrays, valid only during the call; blocking. */
@@ -186,6 +189,17 @@ int sphip_plan_shard(size_t width, size_t height, int n_devices, size_t tile_row
  *        6  the f16 matrix-pipe side product of sp_cylm_scan.h      in f32[12n] 5 triangle values, 5 ray values, P_a (a half), 0
  *                                                                  out f32[2n] the instruction's result, the same 16 products summed in double */
 int sphip_selftest_device(sphip_t* ctx, int what, const void* in, size_t n, void* out);
+
+/* TEST-ONLY: stage 1 of the default scan ALONE -- the conservative reject that decides which (ray, triangle) pairs ever reach
+ * geom::ray_intersect (src/geom.h:197-222) -- for n_rays host rays (a multiple of 64) against the context's scene, formed
+ * exactly as the render kernels form it (same ray setup, same fragment code, same tiles).  A test can then assert, pair by
+ * pair, that no pair the reference accepts has its bit clear, instead of observing the filter only through the closest hit.
+ *   *tiles_out         256-triangle tiles of the scene's stream (call with out_words = NULL first to size the outputs)
+ *   out_words[(k * tiles + t) * 2 + rb]   word of "lane" k (k = 64 b + l) for tile t: bit 31 - (4 f + j) set = the group of four
+ *                      triangles 8 f + 2 j + (l >> 5) of tile t SURVIVES for ray 64 b + (l & 31) + 32 rb (f < 8, j < 4)
+ *   out_order[t * 256 + 4 g + u]          index of the triangle at place u of group g of tile t (n_tris = padding)
+ * Blocking; host pointers; single-device contexts. */
+int sphip_selftest_stage1(sphip_t* ctx, const float* rays, size_t n_rays, uint32_t* out_words, int32_t* out_order, uint32_t* tiles_out);
 
 /* Blocks until the last render on this context has finished, then reports its figures. */
 int sphip_get_stats(sphip_t* ctx, sphip_stats* out);

@@ -30,6 +30,7 @@ SYMBOLS = (
     "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
     "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats", "sphip_viewport_device", "sphip_render_camera",
     "sphip_create_multi", "sphip_device_count", "sphip_plan_tile_rows", "sphip_plan_shard", "sphip_selftest_device",
+    "sphip_kernel_available", "sphip_selftest_stage1",
 )
 GATHER_NONE, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 
@@ -106,6 +107,13 @@ def load():
     L.sphip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sphip_selftest_device.restype = C.c_int
     L.sphip_selftest_device.argtypes = [vp, C.c_int, vp, sz, vp]
+    # older builds (A/B libraries of earlier rounds) lack the next two: bind them when present
+    if hasattr(L, "sphip_kernel_available"):
+        L.sphip_kernel_available.restype = C.c_int
+        L.sphip_kernel_available.argtypes = [C.c_int]
+    if hasattr(L, "sphip_selftest_stage1"):
+        L.sphip_selftest_stage1.restype = C.c_int
+        L.sphip_selftest_stage1.argtypes = [vp, vp, sz, vp, vp, C.POINTER(C.c_uint32)]
     L.sphip_create_multi.restype = C.c_int
     L.sphip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.sphip_device_count.restype = C.c_int
@@ -129,6 +137,16 @@ def kernel_variants():
         out[n.decode()] = i
         i += 1
     return out
+
+
+def available_variants():
+    """ids (> 0) of the kernel variants THIS build of the library carries (the shipped build leaves the earlier filter
+    generations out; a -DSP_ALL_VARIANTS build has them all)."""
+    L = load()
+    ids = sorted(v for v in kernel_variants().values() if v > 0)
+    if not hasattr(L, "sphip_kernel_available"):
+        return ids
+    return [v for v in ids if L.sphip_kernel_available(v)]
 
 
 def plan_tile_rows(height: int, n_devices: int) -> int:
@@ -261,6 +279,35 @@ class Context:
         out = np.zeros(n * k, dtype=dt)
         self._check(self._L.sphip_selftest_device(self._h, what, inp.ctypes.data, n, out.ctypes.data), "sphip_selftest_device")
         return out
+
+    def selftest_stage1(self, rays):
+        """sphip_selftest_stage1 (test-only): stage 1 of the default scan alone for the given rays (padded to a multiple of 64)
+        against the context's scene.  Returns (survive, order): survive[ray, stream position] (bool: the position's group of
+        four triangles survives stage 1 for that ray) and order[stream position] = triangle index (n_tris = padding)."""
+        import numpy as np
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        n_pad = (n + 63) // 64 * 64
+        if n_pad != n:
+            rays = np.concatenate([rays, np.repeat(rays[-1:], n_pad - n, axis=0)])
+        tiles = C.c_uint32(0)
+        self._check(self._L.sphip_selftest_stage1(self._h, None, 0, None, None, C.byref(tiles)), "sphip_selftest_stage1")
+        t = tiles.value
+        words = np.zeros(n_pad * t * 2, dtype=np.uint32)
+        order = np.zeros(t * 256, dtype=np.int32)
+        self._check(self._L.sphip_selftest_stage1(self._h, rays.ctypes.data, n_pad, words.ctypes.data, order.ctypes.data, C.byref(tiles)),
+                    "sphip_selftest_stage1")
+        # words[(64 b + l), tile, rb]: bit 31 - (4 f + j) <-> group 8 f + 2 j + (l >> 5), ray 64 b + (l & 31) + 32 rb
+        w = words.reshape(n_pad // 64, 2, 32, t, 2)                      # [block, half, column, tile, rb]
+        bits = ((w[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)     # [..., k = 4 f + j]
+        k = np.arange(32)
+        surv = np.zeros((n_pad // 64, 64, t, 64), dtype=bool)            # [block, ray in block, tile, group]
+        for hh in range(2):
+            grp = 8 * (k // 4) + 2 * (k % 4) + hh
+            for rb in range(2):
+                surv[:, 32 * rb:32 * rb + 32][:, :, :, grp] = bits[:, hh, :, :, rb, :]
+        surv = np.repeat(surv.reshape(n_pad, t * 64), 4, axis=1)         # per stream position
+        return surv[:n], order
 
     def stats(self) -> dict:
         s = Stats()

@@ -11,8 +11,12 @@
 // single half: the test is invariant under scaling the ray, so the ray is scaled by t = half(P_a)/P_a (|t - 1| <= 2^-11), which
 // makes its P_a exactly a half (when P_a is too small for that, t = 1 and the dropped part, < 2^-22, is added to the margin).
 // One instruction = 32 triangles (A rows) x 32 rays (B columns) = 1024 side products in 32 cycles of the matrix
-// pipe; the VALU is left with x = fma(-H, D, |gm|), the min over a group of four triangles and the sign bit: 2 instructions per pair
-// (tools/mfma16_stage1_bench.hip: 18.1 T pairs/s against 7.5 for the VALU form on the same data).
+// pipe.  What is left for the VALU is the cylinder bound and the sign bit, ONE bound per group of four triangles:
+//     min_i (|gm_i| - H_i D)  >=  min_i |gm_i| - Hmax D      (Hmax = the largest H of the group, D > 0)
+// so  m = min(min3(|g0|, |g1|, |g2|), |g3|),  x = fma(-Hmax, D, m),  sign(x - Dq)  -- 5 instructions per 4 pairs instead of the
+// 8 that four separate x cost (round 2).  It can only keep MORE than the per-triangle form (every triangle of a rejected group
+// has |gm_i| - H_i D > Dq, the condition DESIGN.md 4.2 proves safe), and stage 2 re-tests each triangle of a surviving group with
+// its own H.  The prepass orders every class by H (k_cylm_keys + sp_radix_sort.h), so Hmax ~ H_i and next to nothing is lost.
 //
 // Scaling.  Halves hold 6e-5 .. 65504, so both sides are scaled by EXACT powers of two: S = 2^k in [2Rv, 4Rv) for lengths
 // (Rv = the scene bound of sp_filter_scan.h), s_d = 2^-e for the ray direction (largest |dir| component in [1, 2) afterwards):
@@ -30,12 +34,14 @@
 // nothing is gained from several rays per lane).  A wave owns 64 rays = two column blocks; lane l holds, of ray block rb, column
 // l & 31 -- its own ray when (l >> 5) == rb, its partner's otherwise -- and the rows (triangles) 8j + 4(l >> 5) + i of a
 // fragment: the four i of a j are one GROUP of sp_cyl_scan.h, so the sign bits are per (ray, group) exactly as there.
-// Tile: 256 triangles = 16 KB: [8 chunks][64 groups] float4 as in sp_cyl_scan.h (chunk 7 = the four H^ of the group) followed by
-// the A fragments [8 blocks of 32][64 lanes] x 16 B; 8 fragments x 4 group bits = one 32-bit word per ray block (128 / 192-triangle
-// tiles: -15 % / -4 %).  Build hooks for experiments: SP_EXP_NO_STAGE2 (timing only), SP_DBG_ALLBITS, SP_DBG_PRINT, SP_CYLM_UNPINNED.
+// Tile: 256 triangles = 16 KB: [8 chunks][64 groups] float4 as in sp_cyl_scan.h -- except chunk 7, whose first 16 slots hold the
+// scaled Hmax of the groups, [fragment][lane half] x (the four groups j = 0..3 that half owns): one 16-B read per lane and
+// fragment -- followed by the A fragments [8 blocks of 32][64 lanes] x 16 B; 8 fragments x 4 group bits = one 32-bit word per
+// ray block (128 / 192-triangle tiles: -15 % / -4 %).  Build hooks for experiments: SP_EXP_NO_STAGE2 (timing only), SP_DBG_ALLBITS, SP_DBG_PRINT, SP_CYLM_UNPINNED.
 #pragma once
 
 #include "sp_cyl_scan.h"
+#include "sp_radix_sort.h"
 
 namespace sp {
 
@@ -53,7 +59,10 @@ constexpr uint32_t kMRecQ = kMGroups * 8u;        // 512 float4: the f32 part
 constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 1024 float4 = 16 KB
 static_assert(kMTileQ % 256u == 0u, "whole workgroup LDS-DMA passes");
 static_assert(kMGroups <= 64u && kMBlocks * 4u <= 32u, "6-bit group index in a list entry; one 32-bit word of group bits per ray block");
+static_assert(kMBlocks * 2u <= kMGroups, "the Hmax table fits chunk 7");
 SP_DEV constexpr uint32_t cylm_slot(uint32_t group, uint32_t chunk) { return chunk * kMGroups + group; }
+// scaled Hmax of the four groups 8 tb + 2 j + hh (j = 0..3) that lane half hh owns in fragment tb: component j of this float4
+SP_DEV constexpr uint32_t cylm_hmq(uint32_t tb, uint32_t hh) { return 7u * kMGroups + tb * 2u + hh; }
 
 // length scale of the scene: the power of two in [2 Rv, 4 Rv); 0 = matrix filter off for this scene (Rv outside [1e-30, 1e30])
 SP_DEV float cylm_scale(float rv) {
@@ -79,15 +88,14 @@ SP_DEV void half_split(float v, _Float16& hi, _Float16& lo) {
 	lo = to_half(v - (float)hi);
 }
 
-// triangle `in_tile` of a tile: f32 part as cyl_store (48 groups), scaled H^ into chunk 7, the A-fragment row
+// triangle `in_tile` of a tile: f32 part as cyl_store (chunks 0-6), the A-fragment row
 SP_DEV void cylm_store(float4* __restrict__ tile, uint32_t in_tile, const float4 q0, const float4 q1, float S) {
 	const uint32_t grp = in_tile >> 2, u = in_tile & 3u;
 	tile[cylm_slot(grp, u)] = q0;
 	float* mh = (float*)(tile + cylm_slot(grp, 4u + (u >> 1))) + 2u * (u & 1u);
 	mh[0] = q1.x; mh[1] = q1.y;
 	((float*)(tile + cylm_slot(grp, 6u)))[u] = q1.z;
-	const float k = S > 0.0f ? 256.0f / S : 1.0f, m = S > 0.0f ? 16.0f / S : 0.0f;      // exact: S is a power of two
-	((float*)(tile + cylm_slot(grp, 7u)))[u] = q1.y * k;                                // +-inf stay +-inf
+	const float m = S > 0.0f ? 16.0f / S : 0.0f;                                        // exact: S is a power of two
 	_Float16 bh, bl, ch, cl, xh, xl, yh, yl, zh, zl;
 	half_split(S > 0.0f ? 16.0f * q0.x : 0.0f, bh, bl); half_split(S > 0.0f ? 16.0f * q0.y : 0.0f, ch, cl);
 	half_split(q0.z * m, xh, xl); half_split(q0.w * m, yh, yl); half_split(q1.x * m, zh, zl);
@@ -97,40 +105,74 @@ SP_DEV void cylm_store(float4* __restrict__ tile, uint32_t in_tile, const float4
 	frag[0] = k0; frag[32] = k1;
 }
 
-__global__ void __launch_bounds__(256) k_cylm_scatter(const float* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ block_offsets,
-                                                     const uint32_t* __restrict__ hdr, const unsigned int* __restrict__ bounds, float4* __restrict__ rec) {
-	__shared__ uint32_t wave_cnt[4][3];
-	const uint32_t tid = threadIdx.x, i = blockIdx.x * 256u + tid, wv = tid >> 6, lane = tid & 63u;
-	const float S = cylm_scale(__uint_as_float(bounds[0]));
-	float4 q0, q1;
-	q0 = q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	const int cls = i < n ? cyl_record(tris + (size_t)i * 12, i, q0, q1) : -1;
-	uint32_t rank = 0;
+// ---- prepass 1: sort key of every triangle = class (2 bits) | float bits of H >> 2 (H >= 0 or +inf: the bits order like the
+// values), value = the triangle's index; triangles per class -> hdr[0..2] (zeroed by the host)
+__global__ void __launch_bounds__(256) k_cylm_keys(const float* __restrict__ tris, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                  uint32_t* __restrict__ hdr) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	int cls = -1;
+	if (i < n) {
+		float4 q0, q1;
+		cls = cyl_record(tris + (size_t)i * 12, i, q0, q1);
+		keys[i] = ((uint32_t)cls << 30) | (__float_as_uint(q1.y) >> 2);
+		vals[i] = i;
+	}
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
-		const unsigned long long m = __ballot(cls == k);
-		if (cls == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-		if (lane == 0) wave_cnt[wv][k] = (uint32_t)__popcll(m);
-	}
-	__syncthreads();
-	if (cls >= 0) {
-		for (uint32_t v = 0; v < wv; ++v) rank += wave_cnt[v][cls];
-		const size_t pos = (size_t)hdr[3 + cls] * kMTile + block_offsets[(size_t)blockIdx.x * 3 + cls] + rank;
-		const size_t tile = pos / kMTile;
-		cylm_store(rec + tile * kMTileQ, (uint32_t)(pos - tile * kMTile), q0, q1, S);
+		const int cnt = __syncthreads_count(cls == k);
+		if (threadIdx.x == 0 && cnt) atomicAdd(hdr + k, (uint32_t)cnt);
 	}
 }
 
-__global__ void __launch_bounds__(256) k_cylm_pad(uint32_t* __restrict__ hdr, uint32_t n_tris, const unsigned int* __restrict__ bounds, float4* __restrict__ rec) {
+// ---- prepass 2 (one thread): hdr[3..5] = first tile of each class, hdr[6] = tiles in total, hdr[7] = the length scale S
+__global__ void k_cylm_hdr(uint32_t* __restrict__ hdr, const unsigned int* __restrict__ bounds) {
+	uint32_t tile = 0;
+	for (int k = 0; k < 3; ++k) { hdr[3 + k] = tile; tile += (hdr[k] + kMTile - 1u) / kMTile; }
+	hdr[6] = tile;
+	((float*)hdr)[7] = cylm_scale(__uint_as_float(bounds[0]));
+}
+
+// ---- prepass 3: the triangle at sorted position p (classes in order, ascending H within a class; equal keys in index order:
+// the sort is stable) goes to rank p - (start of its class) of the class's run of tiles
+__global__ void __launch_bounds__(256) k_cylm_scatter(const float* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ sorted,
+                                                     const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
+	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t i = sorted[p];
+	const float S = ((const float*)hdr)[7];
+	float4 q0, q1;
+	const int cls = cyl_record(tris + (size_t)i * 12, i, q0, q1);
+	const uint32_t c0 = cls == 0 ? 0u : cls == 1 ? hdr[0] : hdr[0] + hdr[1];
+	const size_t pos = (size_t)hdr[3 + cls] * kMTile + (p - c0);
+	const size_t tile = pos / kMTile;
+	cylm_store(rec + tile * kMTileQ, (uint32_t)(pos - tile * kMTile), q0, q1, S);
+}
+
+// ---- prepass 4: the ragged end of each class's last tile.  f32 record with H = -inf (stage 2's re-test rejects it; a ray whose
+// filter is off sends it on to the exact test, where index n_tris is a zero exact record: a = 0, rejected at geom.h:204) and a
+// zero A row
+__global__ void __launch_bounds__(256) k_cylm_pad(const uint32_t* __restrict__ hdr, uint32_t n_tris, float4* __restrict__ rec) {
 	const uint32_t k = blockIdx.x, tid = threadIdx.x;
 	const uint32_t n = hdr[k], first = hdr[3 + k] * kMTile;
-	const float S = cylm_scale(__uint_as_float(bounds[0]));
+	const float S = ((const float*)hdr)[7];
 	for (uint32_t pos = n + tid; pos < (n + kMTile - 1u) / kMTile * kMTile; pos += 256u) {
 		const size_t gpos = (size_t)first + pos, tile = gpos / kMTile;
 		cylm_store(rec + tile * kMTileQ, (uint32_t)(gpos - tile * kMTile), make_float4(0.0f, 0.0f, 0.0f, 0.0f),
 		           make_float4(0.0f, -__builtin_inff(), __uint_as_float(n_tris), 0.0f), S);
 	}
-	if (k == 0 && tid == 0) ((float*)hdr)[7] = S;            // the scan reads the scale next to the class table
+}
+
+// ---- prepass 5: Hmax^ = 256 max(H) / S of every group (one thread per group, one block per tile): +inf if the group holds a
+// degenerate triangle (always survives), -inf if it holds nothing but padding (never does)
+__global__ void __launch_bounds__(64) k_cylm_hmax(const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
+	if (blockIdx.x >= hdr[6] || threadIdx.x >= kMGroups) return;
+	float4* tile = rec + (size_t)blockIdx.x * kMTileQ;
+	const uint32_t grp = threadIdx.x, tb = grp >> 3, j = (grp & 7u) >> 1, hh = grp & 1u;
+	const float S = ((const float*)hdr)[7];
+	const float k = S > 0.0f ? 256.0f / S : 1.0f;                                       // exact: S is a power of two
+	const float4 a = tile[cylm_slot(grp, 4u)], b = tile[cylm_slot(grp, 5u)];           // (Mz H Mz H) of triangles 0,1 and 2,3
+	const float hm = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) * k;                       // +-inf stay +-inf
+	((float*)(tile + cylm_hmq(tb, hh)))[j] = hm;
 }
 
 SP_DEV void cylm_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, uint32_t wbase) {
@@ -179,49 +221,42 @@ __global__ void __launch_bounds__(64) k_selftest_cylm(const float* __restrict__ 
 	}
 }
 
-constexpr uint32_t kMCap = 512u;             // list entries per wave and pass (16 bits each: ray << 6 | group)
-
-// Closest hit for the ray of every lane.  Block-uniform call (barriers inside).
-SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlots<1>& s, float (&bd)[1], int (&bi)[1]) {
-	__shared__ float4 sm[2 * kMTileQ];
-	__shared__ unsigned short lst[4 * kMCap];
-	__shared__ uint32_t lcnt[4];
-	__shared__ unsigned long long cell[256];
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u, hh = lane >> 5;
-	unsigned short* const mylst = lst + (tid >> 6) * kMCap;
-	uint32_t* const mycnt = lcnt + (tid >> 6);
-	const float S = ((const float*)cs.hdr)[7];
-
-	// ---- the lane's own ray: the f32 filter state of cyl_setup (stage 2 recomputes x in f32) and its scaled halves
-	CylRay<1> f;
-	cyl_setup<1>(rv, s, f);
-	const float adx = fabsf(s.dir[0].x), ady = fabsf(s.dir[0].y), adz = fabsf(s.dir[0].z);
-	const float on = fabsf(s.o[0].x) + fabsf(s.o[0].y) + fabsf(s.o[0].z);
-	const float dmax = fmaxf(adx, fmaxf(ady, adz));
-	// cyl_setup's verdict (filter on: finite margin) plus the range of the halves; off: zero operands and a margin of +inf
-	const bool on0 = (f.Dq[0] < __builtin_inff()) && (f.Dq[0] > 0.0f) && (S > 0.0f) && (on + 2.0f * rv <= 512.0f * S);
-	const uint32_t ed = (__float_as_uint(dmax) >> 23) & 255u;
-	const float sd0 = on0 ? __uint_as_float((254u - ed) << 23) : 0.0f;                  // 2^-(e-127): dmax * s_d in [1, 2)
-	// the scale factors themselves must stay in range: a 1e-30 scene traversed with 1e-18 directions would make them overflow
-	// (cyl_setup's guards bound |dir| and |dir|(|pos| + 2Rv) from above, not Rv from below against |dir|)
-	const float kP0 = on0 ? sd0 * (16.0f / S) : 0.0f, kC0 = on0 ? sd0 * (256.0f / S) : 0.0f;
-	const bool on_m = on0 && (kC0 < 1e30f) && (kP0 > 1e-30f);
-	const float s_d = on_m ? sd0 : 0.0f;
-	const float kP = on_m ? kP0 : 0.0f, kN = 16.0f * s_d, kC = on_m ? kC0 : 0.0f;
-	const float Dh = on_m ? f.D[0] * s_d : 1.0f;
-	// inactive lane: Dq = -inf (rejected); filter off: +inf; else scaled (exact)
-	const float Dqh = on_m ? f.Dq[0] * kC : (s.act[0] ? __builtin_inff() : -__builtin_inff());
-	// world-frame scaled values; the class rotation below picks (a, b, c) = (x, y, z), (y, z, x), (z, x, y)
-	const float Pw[3] = { f.Pa[0] * kP, f.Pb[0] * kP, f.Pc[0] * kP };                  // cyl_setup leaves class 0: (Pa, Pb, Pc) = (P.x, P.y, P.z)
-	const float Nw[3] = { f.ndx[0] * kN, f.ndy[0] * kN, f.ndz[0] * kN };
-
-	const unsigned long long kNone = ((unsigned long long)__float_as_uint(kMaxDist) << 32) | 0xffffffffull;
-	cell[tid] = kNone;
-
-	// B fragments, D^ and Dq^ of the two ray blocks for class `cls` (lane l: column l & 31 of block rb, K half l >> 5)
+// ---- ray side of stage 1.  The lane's own ray: the f32 filter state of cyl_setup (stage 2 recomputes x in f32) and its scaled
+// values; per class the B fragments, D^ and Dq^ of the wave's two ray blocks (lane l: column l & 31 of block rb, K half l >> 5)
+struct CylmRay {
+	CylRay<1> f;               // f32 state, rotated class by class (Pa = the class's dominant axis)
+	float Pw[3], Nw[3];        // scaled moment and -dir in the world frame
+	float Dh, Dqh;
+	bool on_m;
 	half8 bfr[2];
 	float Dn[2], Dqn[2];
-	auto build_b = [&](uint32_t cls) {
+
+	SP_DEV void setup(float rv, float S, const RaySlots<1>& s) {
+		cyl_setup<1>(rv, s, f);
+		const float adx = fabsf(s.dir[0].x), ady = fabsf(s.dir[0].y), adz = fabsf(s.dir[0].z);
+		const float on = fabsf(s.o[0].x) + fabsf(s.o[0].y) + fabsf(s.o[0].z);
+		const float dmax = fmaxf(adx, fmaxf(ady, adz));
+		// cyl_setup's verdict (filter on: finite margin) plus the range of the halves; off: zero operands and a margin of +inf
+		const bool on0 = (f.Dq[0] < __builtin_inff()) && (f.Dq[0] > 0.0f) && (S > 0.0f) && (on + 2.0f * rv <= 512.0f * S);
+		const uint32_t ed = (__float_as_uint(dmax) >> 23) & 255u;
+		const float sd0 = on0 ? __uint_as_float((254u - ed) << 23) : 0.0f;                  // 2^-(e-127): dmax * s_d in [1, 2)
+		// the scale factors themselves must stay in range: a 1e-30 scene traversed with 1e-18 directions would make them overflow
+		// (cyl_setup's guards bound |dir| and |dir|(|pos| + 2Rv) from above, not Rv from below against |dir|)
+		const float kP0 = on0 ? sd0 * (16.0f / S) : 0.0f, kC0 = on0 ? sd0 * (256.0f / S) : 0.0f;
+		on_m = on0 && (kC0 < 1e30f) && (kP0 > 1e-30f);
+		const float s_d = on_m ? sd0 : 0.0f;
+		const float kP = on_m ? kP0 : 0.0f, kN = 16.0f * s_d, kC = on_m ? kC0 : 0.0f;
+		Dh = on_m ? f.D[0] * s_d : 1.0f;
+		// inactive lane: Dq = -inf (rejected); filter off: +inf; else scaled (exact)
+		Dqh = on_m ? f.Dq[0] * kC : (s.act[0] ? __builtin_inff() : -__builtin_inff());
+		// cyl_setup leaves class 0: (Pa, Pb, Pc) = (P.x, P.y, P.z); build() picks (a, b, c) = (x, y, z), (y, z, x), (z, x, y)
+		Pw[0] = f.Pa[0] * kP; Pw[1] = f.Pb[0] * kP; Pw[2] = f.Pc[0] * kP;
+		Nw[0] = f.ndx[0] * kN; Nw[1] = f.ndy[0] * kN; Nw[2] = f.ndz[0] * kN;
+	}
+
+	// entering class cls (wave-uniform); the f32 state is rotated by the caller
+	SP_DEV void build(uint32_t cls, uint32_t lane) {
+		const uint32_t hh = lane >> 5;
 		const float Pa_ = cls == 0u ? Pw[0] : cls == 1u ? Pw[1] : Pw[2];
 		const float Pb_ = cls == 0u ? Pw[1] : cls == 1u ? Pw[2] : Pw[0], Pc_ = cls == 0u ? Pw[2] : cls == 1u ? Pw[0] : Pw[1];
 		// scale the ray by t so that its P_a is exactly a half
@@ -249,9 +284,69 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			Dn[rb] = __shfl(Dt, src, 64);
 			Dqn[rb] = __shfl(Dqt, src, 64);
 		}
-	};
-	build_b(0u);
+	}
+};
 
+// min(|a|, |b|, |c|, |d|) of four matrix-pipe results.  The results are finite by construction (sums of 16 products of halves), which
+// the compiler cannot know: written with fminf it quiets two of the four inputs first (v_max_f32 x, |x|, |x|: 16 more instructions
+// per fragment), because v_min_f32 in IEEE mode does not return the other operand for a signalling NaN.  gfx950's IEEE-754-2019
+// minimum (v_minimum3_f32: NaN in, NaN out) needs no quieting: two instructions for four values.
+#ifndef SP_CYLM_MIN
+#define SP_CYLM_MIN 1
+#endif
+SP_DEV float min4_abs(float a, float b, float c, float d) {
+#if SP_CYLM_MIN == 1
+	return __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)), __builtin_fabsf(d));
+#elif SP_CYLM_MIN == 2      // median of (|a|, |b|, 0) = min(|a|, |b|): v_med3_f32 is not quieted either
+	return __builtin_fminf(__builtin_fminf(__builtin_amdgcn_fmed3f(__builtin_fabsf(a), __builtin_fabsf(b), 0.0f), __builtin_fabsf(c)), __builtin_fabsf(d));
+#else
+	return __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)), __builtin_fabsf(d));
+#endif
+}
+
+// ---- stage 1 for one fragment (32 triangles) of tile `cur` against the wave's 64 rays: appends 4 bits to word[rb], one per group
+// 8 tb + 2 j + hh (j = 0..3, first appended = highest).  2 LDS reads, 2 matrix instructions, 40 VALU for 2048 pairs.
+SP_DEV void cylm_fragment(const float4* cur, uint32_t tb, uint32_t lane, const CylmRay& R, uint32_t (&word)[2]) {
+	const half8 afr = ((const half8*)(cur + kMRecQ))[tb * 64u + lane];
+	const float4 Hm = cur[cylm_hmq(tb, lane >> 5)];
+	float16v zero;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+	const float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[0], zero, 0, 0, 0);
+	const float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[1], zero, 0, 0, 0);
+#pragma unroll
+	for (int rb = 0; rb < 2; ++rb) {
+		const float16v& g = rb == 0 ? g0 : g1;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float hm = j == 0 ? Hm.x : j == 1 ? Hm.y : j == 2 ? Hm.z : Hm.w;
+			const float m = min4_abs(g[4 * j + 0], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+			const float x = __builtin_fmaf(-hm, R.Dn[rb], m);
+			word[rb] = __builtin_amdgcn_alignbit(word[rb], __float_as_uint(x - R.Dqn[rb]), 31);
+		}
+	}
+}
+
+constexpr uint32_t kMCap = 512u;             // list entries per wave and pass (16 bits each: ray << 6 | group)
+
+// Closest hit for the ray of every lane.  Block-uniform call (barriers inside).
+SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlots<1>& s, float (&bd)[1], int (&bi)[1]) {
+	__shared__ float4 sm[2 * kMTileQ];
+	__shared__ unsigned short lst[4 * kMCap];
+	__shared__ uint32_t lcnt[4];
+	__shared__ unsigned long long cell[256];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u, hh = lane >> 5;
+	unsigned short* const mylst = lst + (tid >> 6) * kMCap;
+	uint32_t* const mycnt = lcnt + (tid >> 6);
+	const float S = ((const float*)cs.hdr)[7];
+
+	CylmRay R;
+	R.setup(rv, S, s);
+	CylRay<1>& f = R.f;
+
+	const unsigned long long kNone = ((unsigned long long)__float_as_uint(kMaxDist) << 32) | 0xffffffffull;
+	cell[tid] = kNone;
+	R.build(0u, lane);
 
 	const uint32_t total_tiles = cs.hdr[6];
 	uint32_t cls = 0;
@@ -266,47 +361,14 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			++cls;
 			// f32 state of stage 2 rotates as in scan_cylw; the halves are rebuilt for the class
 			const float t0 = f.Pa[0]; f.Pa[0] = f.Pb[0]; f.Pb[0] = f.Pc[0]; f.Pc[0] = t0;
-			build_b(cls);
+			R.build(cls, lane);
 		}
 		const float4* cur = sm + (gt & 1u) * kMTileQ;
-		const half8* frags = (const half8*)(cur + kMRecQ);
 		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kMTile;
 		const uint32_t nblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kMTile ? left : kMTile) + 31u) / 32u));
 		// ---- stage 1: word[rb] gets 4 bits per fragment (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
 		uint32_t word[2] = { 0u, 0u };
-		float16v zero;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
-		for (uint32_t tb = 0; tb < nblk; ++tb) {
-			const half8 afr = frags[tb * 64u + lane];
-			float4 Hq[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) Hq[j] = cur[cylm_slot(tb * 8u + 2u * (uint32_t)j + hh, 7u)];
-			const float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[0], zero, 0, 0, 0);
-			const float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[1], zero, 0, 0, 0);
-#ifdef SP_DBG_PRINT
-			if (blockIdx.x == 0 && tid == 0)
-				printf("[cylm] gt %u cls %u tb %u S %g left %u | g0 %g %g %g %g | H %g %g %g %g | Dn %g Dqn %g | afr %g %g %g %g %g %g %g %g | bfr %g %g %g %g %g %g %g %g\n", gt, cls, tb, S, left,
-				       g0[0], g0[1], g0[2], g0[3], Hq[0].x, Hq[0].y, Hq[0].z, Hq[0].w, Dn[0], Dqn[0],
-				       (float)afr[0], (float)afr[1], (float)afr[2], (float)afr[3], (float)afr[4], (float)afr[5], (float)afr[6], (float)afr[7],
-				       (float)bfr[0][0], (float)bfr[0][1], (float)bfr[0][2], (float)bfr[0][3], (float)bfr[0][4], (float)bfr[0][5], (float)bfr[0][6], (float)bfr[0][7]);
-			if (blockIdx.x == 0 && tid == 32)
-				printf("[cylm h1] gt %u tb %u | afr %g %g %g %g %g %g %g %g | bfr %g %g %g %g %g %g %g %g\n", gt, tb,
-				       (float)afr[0], (float)afr[1], (float)afr[2], (float)afr[3], (float)afr[4], (float)afr[5], (float)afr[6], (float)afr[7],
-				       (float)bfr[0][0], (float)bfr[0][1], (float)bfr[0][2], (float)bfr[0][3], (float)bfr[0][4], (float)bfr[0][5], (float)bfr[0][6], (float)bfr[0][7]);
-#endif
-#pragma unroll
-			for (int rb = 0; rb < 2; ++rb) {
-				const float16v& g = rb == 0 ? g0 : g1;
-#pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					const float x0 = __builtin_fmaf(-Hq[j].x, Dn[rb], __builtin_fabsf(g[4 * j + 0])), x1 = __builtin_fmaf(-Hq[j].y, Dn[rb], __builtin_fabsf(g[4 * j + 1]));
-					const float x2 = __builtin_fmaf(-Hq[j].z, Dn[rb], __builtin_fabsf(g[4 * j + 2])), x3 = __builtin_fmaf(-Hq[j].w, Dn[rb], __builtin_fabsf(g[4 * j + 3]));
-					const float m = __builtin_fminf(__builtin_fminf(x0, x1), __builtin_fminf(x2, x3));
-					word[rb] = __builtin_amdgcn_alignbit(word[rb], __float_as_uint(m - Dqn[rb]), 31);
-				}
-			}
-		}
+		for (uint32_t tb = 0; tb < nblk; ++tb) cylm_fragment(cur, tb, lane, R, word);
 		const uint32_t done = nblk * 4u;                              // bits appended; left-align
 #pragma unroll
 		for (int rb = 0; rb < 2; ++rb) word[rb] = done == 0u ? 0u : (word[rb] << (32u - done));
@@ -325,6 +387,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			const uint32_t c = (uint32_t)__builtin_popcount(word[0]) + (uint32_t)__builtin_popcount(word[1]);
 			if (!__any(c != 0u)) break;
 			if (lane == 0) *mycnt = 0u;
+			__builtin_amdgcn_wave_barrier();                             // the reset is issued before any lane's add (one wave: LDS operations stay in order)
 			uint32_t j = c ? atomicAdd(mycnt, c) : 0u;
 			const uint32_t jend = j + c < kMCap ? j + c : kMCap;
 #pragma unroll
@@ -340,6 +403,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				}
 				word[rb] = m;
 			}
+			__builtin_amdgcn_wave_barrier();                             // every lane's entries are issued before the list is read back
 			uint32_t total = *mycnt;
 			total = (uint32_t)__builtin_amdgcn_readfirstlane((int)(total < kMCap ? total : kMCap));
 #ifdef SP_FILTER_STATS
@@ -356,7 +420,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
 				const float Pa = __shfl(f.Pa[0], L, 64), Pb = __shfl(f.Pb[0], L, 64), Pc = __shfl(f.Pc[0], L, 64);
 				const float D = __shfl(f.D[0], L, 64), Dq = __shfl(f.Dq[0], L, 64);
-				// the f32 cylinder test of sp_cyl_scan.h on the group's four records: which of them survive
+				// the f32 cylinder test of sp_cyl_scan.h on the group's four records, each with its own H: which of them survive
 				uint32_t cand = 0;
 				const CylmGroup G = cylm_group(cur, grp);
 				const float4 gi = cur[cylm_slot(grp, 6u)];
@@ -398,6 +462,45 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 	const unsigned long long k = cell[tid];
 	bd[0] = __uint_as_float((uint32_t)(k >> 32));
 	bi[0] = (int)(uint32_t)k;
+}
+
+// ---- test-only (sphip_selftest_stage1): stage 1 ALONE, exactly as scan_cylm runs it (same ray setup, same fragment function,
+// same tiles), for 64 rays per one-wave workgroup (n_rays a multiple of 64).  out_words[((block * 64 + lane) * tiles + tile) * 2 + rb] = the lane's word:
+// bit 31 - (4 tb + j) = group 8 tb + 2 j + (lane >> 5) of that tile survives for ray 64 block + (lane & 31) + 32 rb.
+// Block 0 also writes the stream order: out_order[tile * kMTile + 4 group + u] = triangle index at that place (n_tris = padding).
+__global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict__ rays, uint32_t n_rays, const CylStream cs, const unsigned int* __restrict__ bounds,
+                                                      uint32_t* __restrict__ out_words, int* __restrict__ out_order) {
+	__shared__ float4 sm[kMTileQ];
+	const uint32_t lane = threadIdx.x;
+	const float rv = __uint_as_float(bounds[0]);
+	const float S = ((const float*)cs.hdr)[7];
+	const uint32_t k = blockIdx.x * 64u + lane, kk = k < n_rays ? k : n_rays - 1u;
+	RaySlots<1> s;
+	const float* p = rays + (size_t)kk * 6;
+	s.o[0] = mk3(p[0], p[1], p[2]); s.dir[0] = mk3(p[3], p[4], p[5]); s.src[0] = -1; s.act[0] = true;
+	CylmRay R;
+	R.setup(rv, S, s);
+	R.build(0u, lane);
+	const uint32_t total_tiles = cs.hdr[6];
+	uint32_t cls = 0;
+	for (uint32_t gt = 0; gt < total_tiles; ++gt) {
+		while (cls < 2u && gt >= cs.hdr[4 + cls]) { ++cls; R.build(cls, lane); }
+		__syncthreads();
+		for (uint32_t q = lane; q < kMTileQ; q += 64u) sm[q] = cs.rec[(size_t)gt * kMTileQ + q];
+		__syncthreads();
+		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kMTile;
+		const uint32_t nblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kMTile ? left : kMTile) + 31u) / 32u));
+		uint32_t word[2] = { 0u, 0u };
+		for (uint32_t tb = 0; tb < nblk; ++tb) cylm_fragment(sm, tb, lane, R, word);
+		const uint32_t done = nblk * 4u;
+#pragma unroll
+		for (int rb = 0; rb < 2; ++rb) if (k < n_rays) out_words[((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb] = done == 0u ? 0u : (word[rb] << (32u - done));
+		if (blockIdx.x == 0) {
+			const float4 gi = sm[cylm_slot(lane, 6u)];
+			int* o = out_order + (size_t)gt * kMTile + 4u * lane;
+			o[0] = (int)__float_as_uint(gi.x); o[1] = (int)__float_as_uint(gi.y); o[2] = (int)__float_as_uint(gi.z); o[3] = (int)__float_as_uint(gi.w);
+		}
+	}
 }
 
 } // namespace sp

@@ -57,8 +57,7 @@ constexpr int kQCap = SP_QCAP;   // queue entries per lane (u16); 12 KB, keeps 4
 
 // filter record: 48 B = 3 x float4, produced by k_repack_filter
 //   q0 = w.x w.y w.z Mc.x   q1 = Mc.y Mc.z h.x h.y   q2 = h.z 0 0 0
-__global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__ tris, float4* __restrict__ filt,
-                                                      unsigned int* __restrict__ bounds, uint32_t n, uint32_t n_padded) {
+__global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__ tris, float4* __restrict__ filt, uint32_t n, uint32_t n_padded) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_padded) return;
 	if (i >= n) {
@@ -100,15 +99,6 @@ __global__ void __launch_bounds__(256) k_repack_filter(const float* __restrict__
 	filt[(size_t)i * 3 + 0] = make_float4(wx, wy, wz, mcx);
 	filt[(size_t)i * 3 + 1] = make_float4(mcy, mcz, hx, hy);
 	filt[(size_t)i * 3 + 2] = make_float4(hz, 0.0f, 0.0f, 0.0f);
-	// scene bound Rv >= every vertex norm, as 1-norms (>= 2-norm); non-negative floats order like their bit patterns;
-	// a NaN or inf coordinate yields a bit pattern >= inf, which turns the filter off in the kernels
-	float r = 0.0f;
-#pragma unroll
-	for (int k = 0; k < 3; ++k) {
-		const float s = fabsf(t[3 * k]) + fabsf(t[3 * k + 1]) + fabsf(t[3 * k + 2]);
-		r = (s > r || s != s) ? s : r;
-	}
-	atomicMax(bounds, __float_as_uint(r) & 0x7fffffffu);
 }
 
 template <int R>

@@ -57,8 +57,9 @@ __global__ void __launch_bounds__(256) k_resolve(const KArgs a) {
 }
 
 // ---- repack: AoS geom::triangle -> scan records.  e1/e2 are the single float subtractions of
-// geom.h:200-201, hoisted out of the per-ray test (same bits).
-__global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, float4* __restrict__ scan, uint32_t n, uint32_t n_padded) {
+// geom.h:200-201, hoisted out of the per-ray test (same bits).  Also the scene bound Rv (bounds[0], zeroed by the host) that the
+// margins of the two-stage scans are built from.
+__global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, float4* __restrict__ scan, unsigned int* __restrict__ bounds, uint32_t n, uint32_t n_padded) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n_padded) return;
 	if (i >= n) {   // padding record: e1 = e2 = 0 -> a = 0 -> rejected at geom.h:204, can never be hit
@@ -73,6 +74,15 @@ __global__ void __launch_bounds__(256) k_repack(const float* __restrict__ tris, 
 	scan[(size_t)i * 3 + 0] = make_float4(v0x, v0y, v0z, e1x);
 	scan[(size_t)i * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
 	scan[(size_t)i * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+	// scene bound Rv >= every vertex norm, as 1-norms (>= 2-norm); non-negative floats order like their bit patterns;
+	// a NaN or inf coordinate yields a bit pattern >= inf, which turns the filter off in the kernels
+	float r = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const float s = fabsf(t[3 * k]) + fabsf(t[3 * k + 1]) + fabsf(t[3 * k + 2]);
+		r = (s > r || s != s) ? s : r;
+	}
+	atomicMax(bounds, __float_as_uint(r) & 0x7fffffffu);
 }
 
 // ---- view::camera::get_viewport (view.h:94-132) on the device: one thread per pixel.

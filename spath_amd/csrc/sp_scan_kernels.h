@@ -19,8 +19,8 @@ struct ScanSrc {
 template <int R, int SCAN>
 SP_DEV void two_stage_scan(const KArgs& a, const ScanSrc& src, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
 	if constexpr (SCAN == 3) { static_assert(R == 1, "scan_cylm: one ray per lane"); scan_cylm(a, src.cylm, rv, s, bd, bi); }
-	else if (SCAN == 2) scan_cylw<R>(a, src.cyl, rv, s, bd, bi);
-	else if (SCAN == 1) scan_cyl<R>(a, src.cyl, rv, s, bd, bi);
+	else if constexpr (SCAN == 2) scan_cylw<R>(a, src.cyl, rv, s, bd, bi);
+	else if constexpr (SCAN == 1) scan_cyl<R>(a, src.cyl, rv, s, bd, bi);
 	else scan_filter<R>(a, src.filt, rv, s, bd, bi);
 }
 

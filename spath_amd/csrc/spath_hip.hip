@@ -40,8 +40,9 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, bvh_sort, bvh_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim, cylm_rec, cylm_cnt, cylm_hdr;
-	bool bvh_valid = false;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, sort_kv, sort_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim, cylm_rec, cylm_hdr;
+	// record streams beyond the exact one are derived from `tris` the first time a kernel variant that reads them runs on the scene
+	bool bvh_valid = false, filt_valid = false, cyl_valid = false, cylm_valid = false;
 	uint32_t bvh_leaves = 0;
 	size_t n_tris = 0;
 	bool have_scene = false;
@@ -98,7 +99,8 @@ const char* const kVariantNames[kVariantLast + 1] = { "auto", "rpl_sload", "rpl_
                                                       "accel_lbvh", "rpl_cyl1", "rpl_cyl2", "rpl_cyl4", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4", "rpl_cylw4s", "rpl_cylm" };
 
 // the two-stage scan variants: paths per lane (R), whether the R paths are consecutive samples of ONE pixel (split) or R
-// pixels, and the scan generation (0 = slab filter + LDS queues, sp_filter_scan.h; 1 = cylinder filter + bit words, sp_cyl_scan.h)
+// pixels, and the scan generation (0 = slab filter + LDS queues, sp_filter_scan.h; 1 = cylinder filter + bit words, sp_cyl_scan.h;
+// 2 = the same with stage 2 shared by the wave; 3 = stage 1 on the f16 matrix pipe, sp_cylm_scan.h: the default)
 struct TwoStage { int R; bool split; int scan; };
 bool two_stage(int variant, TwoStage* out) {
 	static const TwoStage tab[kVariantLast + 1] = { {0, false, 0}, {0, false, 0}, {0, false, 0}, {2, false, 0}, {4, false, 0}, {1, false, 0}, {2, true, 0}, {4, true, 0},
@@ -108,56 +110,116 @@ bool two_stage(int variant, TwoStage* out) {
 	return true;
 }
 
-int pick_variant(int flags, size_t n_tris, size_t n_rays, int mode, size_t n_samples) {
+// The shipped library carries the exact-only scans (1, 2), the opt-in BVH (8), one f32 cylinder scan for A/B runs (15) and the
+// default (16).  The slab-filter generation and the per-lane cylinder variants are compiled only with -DSP_ALL_VARIANTS (soak and
+// experiment builds: tools/).
+bool variant_built(int v) {
+#ifdef SP_ALL_VARIANTS
+	return v >= 1 && v <= kVariantLast;
+#else
+	return v == 1 || v == 2 || v == kVariantAccel || v == 15 || v == 16;
+#endif
+}
+
+int pick_variant(int flags, size_t n_tris) {
 	if (flags & SPHIP_FLAG_ACCEL) return kVariantAccel;
 	const int v = flags & SPHIP_KERNEL_MASK;
 	if (v >= 1 && v <= kVariantLast) return v;
 	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
 	// The third-generation scan (sp_cylm_scan.h: stage 1 on the f16 matrix pipe, one ray per lane) for every mode; sample chunks
-	// (launch_render) supply the workgroups a small frame lacks.  The earlier generations stay selectable through the flags:
-	// 15 / 12 = 4 / 2 consecutive samples of a pixel per lane with the f32 VALU stage 1 (14 / 10 / 9 for one scan per ray).
-	(void)n_rays; (void)mode; (void)n_samples;
+	// (launch_render) supply the workgroups a small frame lacks.
 	return 16;
 }
 
+// exact records + scene bound: what every variant reads.  The other streams are built on first use (ensure_* below).
 int repack(sphip_ctx* c, hipStream_t st) {
 	const uint32_t n = (uint32_t)c->n_tris;
-	const uint32_t n_pad = (n / sp::kTile + 1) * sp::kTile;      // whole LDS tiles and at least one zero record behind n (index n: the padding of sp_cyl_scan.h points at it)
-	int rc = ensure(c, c->scan, (size_t)n_pad * 48);
-	if (rc) return rc;
-	hipLaunchKernelGGL(sp::k_repack, dim3((n_pad + 255) / 256), dim3(256), 0, st,
-	                   (const float*)c->tris.p, (float4*)c->scan.p, n, n_pad);
-	HIP_TRY(c, hipGetLastError());
-	// filter records + scene bound for the two-stage scan (sp_filter_scan.h)
-	if ((rc = ensure(c, c->filt, (size_t)n_pad * 48)) || (rc = ensure(c, c->bounds, 256))) return rc;
+	const uint32_t n_pad = (n / sp::kTile + 1) * sp::kTile;      // whole LDS tiles and at least one zero record behind n (index n: the padding of the two-stage streams points at it)
+	int rc;
+	if ((rc = ensure(c, c->scan, (size_t)n_pad * 48)) || (rc = ensure(c, c->bounds, 256))) return rc;
 	HIP_TRY(c, hipMemsetAsync(c->bounds.p, 0, 256, st));
-	hipLaunchKernelGGL(sp::k_repack_filter, dim3((n_pad + 255) / 256), dim3(256), 0, st,
-	                   (const float*)c->tris.p, (float4*)c->filt.p, (unsigned int*)c->bounds.p, n, n_pad);
+	hipLaunchKernelGGL(sp::k_repack, dim3((n_pad + 255) / 256), dim3(256), 0, st,
+	                   (const float*)c->tris.p, (float4*)c->scan.p, (unsigned int*)c->bounds.p, n, n_pad);
 	HIP_TRY(c, hipGetLastError());
-	// class-sorted cylinder records (sp_cyl_scan.h): count per block -> offsets -> scatter -> pad, all on the device
-	{
-		const uint32_t nblocks = (n + 255) / 256;
-		if ((rc = ensure(c, c->cyl_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cyl_hdr, 256)) ||
-		    (rc = ensure(c, c->cyl_rec, ((size_t)n / sp::kCylTile + 4) * sp::kCylTile * 32))) return rc;
-		hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cyl_cnt.p);
-		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cyl_cnt.p, nblocks, (uint32_t*)c->cyl_hdr.p, sp::kCylTile);
-		hipLaunchKernelGGL(sp::k_cyl_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cyl_cnt.p,
-		                   (const uint32_t*)c->cyl_hdr.p, (float4*)c->cyl_rec.p);
-		hipLaunchKernelGGL(sp::k_cyl_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)c->cyl_hdr.p, n, (float4*)c->cyl_rec.p);
-		// the same classes in 192-triangle tiles with the f16 matrix fragments (sp_cylm_scan.h)
-		if ((rc = ensure(c, c->cylm_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cylm_hdr, 256)) ||
-		    (rc = ensure(c, c->cylm_rec, ((size_t)n / sp::kMTile + 4) * sp::kMTileQ * 16))) return rc;
-		hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cylm_cnt.p);
-		hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cylm_cnt.p, nblocks, (uint32_t*)c->cylm_hdr.p, sp::kMTile);
-		hipLaunchKernelGGL(sp::k_cylm_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cylm_cnt.p,
-		                   (const uint32_t*)c->cylm_hdr.p, (const unsigned int*)c->bounds.p, (float4*)c->cylm_rec.p);
-		hipLaunchKernelGGL(sp::k_cylm_pad, dim3(3), dim3(256), 0, st, (uint32_t*)c->cylm_hdr.p, n, (const unsigned int*)c->bounds.p, (float4*)c->cylm_rec.p);
-		HIP_TRY(c, hipGetLastError());
-	}
 	c->have_scene = true;
-	c->bvh_valid = false;
+	c->bvh_valid = c->filt_valid = c->cyl_valid = c->cylm_valid = false;
 	return SPHIP_OK;
 }
+
+// stable radix sort of n (key, value) pairs held in c->sort_kv as keys[2][n], vals[2][n] (sp_radix_sort.h); returns which half holds the result
+int radix_sort(sphip_ctx* c, uint32_t n, uint32_t key_bits, hipStream_t st, int* out_half) {
+	const uint32_t rs_blocks = (n + sp::kRsPerBlock - 1) / sp::kRsPerBlock;
+	int rc = ensure(c, c->sort_hist, (size_t)rs_blocks * 16 * 4);
+	if (rc) return rc;
+	uint32_t* keys[2] = { (uint32_t*)c->sort_kv.p, (uint32_t*)c->sort_kv.p + (size_t)n };
+	uint32_t* vals[2] = { (uint32_t*)c->sort_kv.p + (size_t)2 * n, (uint32_t*)c->sort_kv.p + (size_t)3 * n };
+	int cur = 0;
+	for (uint32_t shift = 0; shift < key_bits; shift += 4, cur ^= 1) {
+		hipLaunchKernelGGL(sp::k_rs_hist, dim3(rs_blocks), dim3(256), 0, st, (const uint32_t*)keys[cur], n, shift, rs_blocks, (uint32_t*)c->sort_hist.p);
+		hipLaunchKernelGGL(sp::k_rs_scan, dim3(1), dim3(256), 0, st, (uint32_t*)c->sort_hist.p, rs_blocks * 16u);
+		hipLaunchKernelGGL(sp::k_rs_scatter, dim3(rs_blocks), dim3(256), 0, st, (const uint32_t*)keys[cur], (const uint32_t*)vals[cur], n, shift, rs_blocks,
+		                   (const uint32_t*)c->sort_hist.p, keys[cur ^ 1], vals[cur ^ 1]);
+	}
+	HIP_TRY(c, hipGetLastError());
+	*out_half = cur;
+	return SPHIP_OK;
+}
+
+// ---- the default scan's stream (sp_cylm_scan.h): classes by dominant axis, ascending cylinder radius within a class (device sort),
+// 256-triangle tiles of f32 records + f16 matrix fragments + the per-group Hmax table
+int ensure_cylm(sphip_ctx* c, hipStream_t st) {
+	if (c->cylm_valid) return SPHIP_OK;
+	const uint32_t n = (uint32_t)c->n_tris, nblocks = (n + 255) / 256, max_tiles = n / sp::kMTile + 4;
+	int rc;
+	if ((rc = ensure(c, c->sort_kv, (size_t)n * 16)) || (rc = ensure(c, c->cylm_hdr, 256)) ||
+	    (rc = ensure(c, c->cylm_rec, (size_t)max_tiles * sp::kMTileQ * 16))) return rc;
+	uint32_t* keys = (uint32_t*)c->sort_kv.p;
+	uint32_t* vals = (uint32_t*)c->sort_kv.p + (size_t)2 * n;
+	uint32_t* hdr = (uint32_t*)c->cylm_hdr.p;
+	HIP_TRY(c, hipMemsetAsync(hdr, 0, 256, st));
+	hipLaunchKernelGGL(sp::k_cylm_keys, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, keys, vals, hdr);
+	int half = 0;
+	if ((rc = radix_sort(c, n, 32, st, &half))) return rc;
+	hipLaunchKernelGGL(sp::k_cylm_hdr, dim3(1), dim3(1), 0, st, hdr, (const unsigned int*)c->bounds.p);
+	hipLaunchKernelGGL(sp::k_cylm_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)(vals + (size_t)half * n),
+	                   (const uint32_t*)hdr, (float4*)c->cylm_rec.p);
+	hipLaunchKernelGGL(sp::k_cylm_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)hdr, n, (float4*)c->cylm_rec.p);
+	hipLaunchKernelGGL(sp::k_cylm_hmax, dim3(max_tiles), dim3(64), 0, st, (const uint32_t*)hdr, (float4*)c->cylm_rec.p);
+	HIP_TRY(c, hipGetLastError());
+	c->cylm_valid = true;
+	return SPHIP_OK;
+}
+
+// ---- class-sorted f32 cylinder records (sp_cyl_scan.h): count per block -> offsets -> scatter -> pad, all on the device
+int ensure_cyl(sphip_ctx* c, hipStream_t st) {
+	if (c->cyl_valid) return SPHIP_OK;
+	const uint32_t n = (uint32_t)c->n_tris, nblocks = (n + 255) / 256;
+	int rc;
+	if ((rc = ensure(c, c->cyl_cnt, (size_t)nblocks * 3 * sizeof(uint32_t))) || (rc = ensure(c, c->cyl_hdr, 256)) ||
+	    (rc = ensure(c, c->cyl_rec, ((size_t)n / sp::kCylTile + 4) * sp::kCylTile * 32))) return rc;
+	hipLaunchKernelGGL(sp::k_cyl_count, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (uint32_t*)c->cyl_cnt.p);
+	hipLaunchKernelGGL(sp::k_cyl_offsets, dim3(1), dim3(256), 0, st, (uint32_t*)c->cyl_cnt.p, nblocks, (uint32_t*)c->cyl_hdr.p, sp::kCylTile);
+	hipLaunchKernelGGL(sp::k_cyl_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)c->cyl_cnt.p,
+	                   (const uint32_t*)c->cyl_hdr.p, (float4*)c->cyl_rec.p);
+	hipLaunchKernelGGL(sp::k_cyl_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)c->cyl_hdr.p, n, (float4*)c->cyl_rec.p);
+	HIP_TRY(c, hipGetLastError());
+	c->cyl_valid = true;
+	return SPHIP_OK;
+}
+
+#ifdef SP_ALL_VARIANTS
+// ---- slab records of the first-generation scan (sp_filter_scan.h)
+int ensure_filt(sphip_ctx* c, hipStream_t st) {
+	if (c->filt_valid) return SPHIP_OK;
+	const uint32_t n = (uint32_t)c->n_tris, n_pad = (n / sp::kTile + 1) * sp::kTile;
+	int rc = ensure(c, c->filt, (size_t)n_pad * 48);
+	if (rc) return rc;
+	hipLaunchKernelGGL(sp::k_repack_filter, dim3((n_pad + 255) / 256), dim3(256), 0, st, (const float*)c->tris.p, (float4*)c->filt.p, n, n_pad);
+	HIP_TRY(c, hipGetLastError());
+	c->filt_valid = true;
+	return SPHIP_OK;
+}
+#endif
 
 // ---- linear BVH for SPHIP_FLAG_ACCEL (sp_bvh.h), built on the device (sp_bvh_build.h) the first time a scene is rendered with the flag
 int ensure_bvh(sphip_ctx* c, hipStream_t st) {
@@ -165,27 +227,21 @@ int ensure_bvh(sphip_ctx* c, hipStream_t st) {
 	const uint32_t n = (uint32_t)c->n_tris;
 	uint32_t nl = 1;
 	while ((uint64_t)nl * 4 < n) nl <<= 1;                 // leaves of 4 triangles, padded to a power of two (complete tree in heap order)
-	const uint32_t nblocks = (n + 255) / 256, rs_blocks = (n + sp::kRsPerBlock - 1) / sp::kRsPerBlock;
+	const uint32_t nblocks = (n + 255) / 256;
 	int rc;
 	if ((rc = ensure(c, c->bvh_nodes, (size_t)2 * nl * 32)) || (rc = ensure(c, c->bvh_rec, ((size_t)nl * 4 + sp::kBvhMaxBig) * 48)) ||
-	    (rc = ensure(c, c->bvh_idx, ((size_t)nl * 4 + sp::kBvhMaxBig) * 4)) || (rc = ensure(c, c->bvh_sort, (size_t)n * 16)) ||
-	    (rc = ensure(c, c->bvh_hist, (size_t)rs_blocks * 16 * 4)) || (rc = ensure(c, c->bvh_meta, 256))) return rc;
+	    (rc = ensure(c, c->bvh_idx, ((size_t)nl * 4 + sp::kBvhMaxBig) * 4)) || (rc = ensure(c, c->sort_kv, (size_t)n * 16)) ||
+	    (rc = ensure(c, c->bvh_meta, 256))) return rc;
 	uint32_t* meta = (uint32_t*)c->bvh_meta.p;
-	uint32_t* keys[2] = { (uint32_t*)c->bvh_sort.p, (uint32_t*)c->bvh_sort.p + (size_t)n };
-	uint32_t* vals[2] = { (uint32_t*)c->bvh_sort.p + (size_t)2 * n, (uint32_t*)c->bvh_sort.p + (size_t)3 * n };
+	uint32_t* vals[2] = { (uint32_t*)c->sort_kv.p + (size_t)2 * n, (uint32_t*)c->sort_kv.p + (size_t)3 * n };
 	const float* tris = (const float*)c->tris.p;
 	const dim3 b256(256);
 	hipLaunchKernelGGL(sp::k_bvh_meta_init, dim3(1), b256, 0, st, meta);
 	hipLaunchKernelGGL(sp::k_bvh_box, dim3(nblocks), b256, 0, st, tris, n, meta);
 	hipLaunchKernelGGL(sp::k_bvh_count_big, dim3(nblocks), b256, 0, st, tris, n, meta);
-	hipLaunchKernelGGL(sp::k_bvh_keys, dim3(nblocks), b256, 0, st, tris, n, meta, keys[0], vals[0]);
+	hipLaunchKernelGGL(sp::k_bvh_keys, dim3(nblocks), b256, 0, st, tris, n, meta, (uint32_t*)c->sort_kv.p, vals[0]);
 	int cur = 0;
-	for (uint32_t shift = 0; shift < 32; shift += 4, cur ^= 1) {       // stable LSD radix sort by (Morton code; big triangles last)
-		hipLaunchKernelGGL(sp::k_rs_hist, dim3(rs_blocks), b256, 0, st, (const uint32_t*)keys[cur], n, shift, rs_blocks, (uint32_t*)c->bvh_hist.p);
-		hipLaunchKernelGGL(sp::k_rs_scan, dim3(1), b256, 0, st, (uint32_t*)c->bvh_hist.p, rs_blocks * 16u);
-		hipLaunchKernelGGL(sp::k_rs_scatter, dim3(rs_blocks), b256, 0, st, (const uint32_t*)keys[cur], (const uint32_t*)vals[cur], n, shift, rs_blocks,
-		                   (const uint32_t*)c->bvh_hist.p, keys[cur ^ 1], vals[cur ^ 1]);
-	}
+	if ((rc = radix_sort(c, n, 32, st, &cur))) return rc;            // stable LSD radix sort by (Morton code; big triangles last)
 	hipLaunchKernelGGL(sp::k_bvh_leaves, dim3((nl + 255) / 256), b256, 0, st, tris, n, (const uint32_t*)meta, (const uint32_t*)vals[cur], nl,
 	                   (float4*)c->bvh_nodes.p, (float4*)c->bvh_rec.p, (int*)c->bvh_idx.p);
 	hipLaunchKernelGGL(sp::k_bvh_bigs, dim3(1), b256, 0, st, tris, n, (const uint32_t*)meta, (const uint32_t*)vals[cur], nl, (float4*)c->bvh_rec.p, (int*)c->bvh_idx.p);
@@ -233,7 +289,9 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	}
 	a.inv_n = (float)(1.0 / (double)(n_samples ? n_samples : 1));      // cpu_renderer.cpp:77
 
-	const int variant = pick_variant(flags, c->n_tris, n_rays, mode, n_samples);
+	const int variant = pick_variant(flags, c->n_tris);
+	if (!variant_built(variant))
+		return fail(c, SPHIP_E_INVALID, "kernel variant %d (%s) is not compiled into this build of libspath_hip (rebuild with -DSP_ALL_VARIANTS)", variant, kVariantNames[variant]);
 	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, 8 * sizeof(unsigned long long), st));
 	// sample chunks: the filter kernels keep 1024 workgroups resident (256 CUs x 4); a launch of only a few times that
 	// many ends with a long tail (its time is that of the slowest workgroup, ~12 % above the mean when everything starts
@@ -254,12 +312,16 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		if (chunks > 1 && !forced) {
 			// the split is an optimisation: it must never make a render fail that would fit unsplit (52 B per pixel).
 			// Keep the scratch under the cap and under 90 % of what the device has free beyond the cached buffers.
+			// (the device is asked for its free memory only when a buffer has to grow: not on every frame of a running viewer)
 			size_t free_b = 0, total_b = 0;
-			if (samp_bytes > kChunkMaxBytes || hipMemGetInfo(&free_b, &total_b) != hipSuccess) chunks = 1;
+			bool asked = false;
+			if (samp_bytes > kChunkMaxBytes) chunks = 1;
 			const uint64_t lanes = (uint64_t)((n_rays + 1023) / 1024 * 1024) * slots;
 			while (chunks > 1) {
 				const uint64_t work_bytes = lanes * chunks * 52;
 				const uint64_t need = (samp_bytes > c->samp.cap ? samp_bytes : 0) + (work_bytes > c->work.cap ? work_bytes : 0);
+				if (need == 0) break;
+				if (!asked) { asked = true; if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { chunks = 1; break; } }
 				if (need <= (uint64_t)((double)free_b * 0.9)) break;
 				chunks /= 2;
 			}
@@ -288,6 +350,12 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		acc = (float*)((char*)c->work.p + (size_t)n_work * 40);
 	}
 	sp::ScanSrc src2{};
+	// the record stream the variant reads, derived from the scene on first use
+	if (is_ts && ts.scan == 3 && (rc = ensure_cylm(c, st))) return rc;
+	if (is_ts && (ts.scan == 1 || ts.scan == 2) && (rc = ensure_cyl(c, st))) return rc;
+#ifdef SP_ALL_VARIANTS
+	if (is_ts && ts.scan == 0 && (rc = ensure_filt(c, st))) return rc;
+#endif
 	src2.filt = (const float4*)c->filt.p;
 	src2.cyl.rec = (const float4*)c->cyl_rec.p;
 	src2.cyl.hdr = (const uint32_t*)c->cyl_hdr.p;
@@ -311,10 +379,12 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		h.n_chunks = 0; h.samp = nullptr;
 		const int* no_src = nullptr;
 #define SP_PRIM(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, h, src2, bnd, no_src, oi, od)
-		if (ts.scan == 0) { if (ts.R == 4) SP_PRIM(4, 0); else if (ts.R == 2) SP_PRIM(2, 0); else SP_PRIM(1, 0); }
-		else if (ts.scan == 3) SP_PRIM(1, 3);
+		if (ts.scan == 3) SP_PRIM(1, 3);
 		else if (ts.scan == 2) SP_PRIM(4, 2);
+#ifdef SP_ALL_VARIANTS
+		else if (ts.scan == 0) { if (ts.R == 4) SP_PRIM(4, 0); else if (ts.R == 2) SP_PRIM(2, 0); else SP_PRIM(1, 0); }
 		else              { if (ts.R == 4) SP_PRIM(4, 1); else if (ts.R == 2) SP_PRIM(2, 1); else SP_PRIM(1, 1); }
+#endif
 #undef SP_PRIM
 		a.prim_idx = oi; a.prim_d = od;
 		prim_pass = true;
@@ -327,10 +397,12 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		int* oi = (int*)d_rgba; float* od = (float*)d_accum;
 		if (is_ts) {
 #define SP_HIT(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd, d_src, oi, od)
-			if (ts.scan == 0) { if (ts.R == 4) SP_HIT(4, 0); else if (ts.R == 2) SP_HIT(2, 0); else SP_HIT(1, 0); }
-			else if (ts.scan == 3) SP_HIT(1, 3);
+			if (ts.scan == 3) SP_HIT(1, 3);
 			else if (ts.scan == 2) SP_HIT(4, 2);
+#ifdef SP_ALL_VARIANTS
+			else if (ts.scan == 0) { if (ts.R == 4) SP_HIT(4, 0); else if (ts.R == 2) SP_HIT(2, 0); else SP_HIT(1, 0); }
 			else              { if (ts.R == 4) SP_HIT(4, 1); else if (ts.R == 2) SP_HIT(2, 1); else SP_HIT(1, 1); }
+#endif
 #undef SP_HIT
 		}
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_hit<2>, grid, block, 0, st, a, d_src, oi, od);
@@ -338,10 +410,12 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	} else if (mode == SPHIP_MODE_FLAT) {
 		if (is_ts) {
 #define SP_FLAT(R_, S_) hipLaunchKernelGGL((sp::k_flat_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd)
-			if (ts.scan == 0) { if (ts.R == 4) SP_FLAT(4, 0); else if (ts.R == 2) SP_FLAT(2, 0); else SP_FLAT(1, 0); }
-			else if (ts.scan == 3) SP_FLAT(1, 3);
+			if (ts.scan == 3) SP_FLAT(1, 3);
 			else if (ts.scan == 2) SP_FLAT(4, 2);
+#ifdef SP_ALL_VARIANTS
+			else if (ts.scan == 0) { if (ts.R == 4) SP_FLAT(4, 0); else if (ts.R == 2) SP_FLAT(2, 0); else SP_FLAT(1, 0); }
 			else              { if (ts.R == 4) SP_FLAT(4, 1); else if (ts.R == 2) SP_FLAT(2, 1); else SP_FLAT(1, 1); }
+#endif
 #undef SP_FLAT
 		}
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_flat<2>, grid, block, 0, st, a);
@@ -349,17 +423,18 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	} else {
 		if (is_ts) {
 #define SP_PT(R_, SPLIT_, S_) hipLaunchKernelGGL((sp::k_pt_filter<R_, SPLIT_, S_>), grid_pt, block, 0, st, a, src2, bnd, hist, acc, n_work)
-			if (ts.scan == 0) {
+			if (ts.scan == 3) SP_PT(1, false, 3);
+			else if (ts.scan == 2 && ts.split) SP_PT(4, true, 2);
+#ifdef SP_ALL_VARIANTS
+			else if (ts.scan == 2) SP_PT(4, false, 2);
+			else if (ts.scan == 0) {
 				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 0); else SP_PT(2, true, 0); }
 				else          { if (ts.R == 4) SP_PT(4, false, 0); else if (ts.R == 2) SP_PT(2, false, 0); else SP_PT(1, false, 0); }
-			} else if (ts.scan == 3) {
-				SP_PT(1, false, 3);
-			} else if (ts.scan == 2) {
-				if (ts.split) SP_PT(4, true, 2); else SP_PT(4, false, 2);
 			} else {
 				if (ts.split) { if (ts.R == 4) SP_PT(4, true, 1); else SP_PT(2, true, 1); }
 				else          { if (ts.R == 4) SP_PT(4, false, 1); else if (ts.R == 2) SP_PT(2, false, 1); else SP_PT(1, false, 1); }
 			}
+#endif
 #undef SP_PT
 		}
 		else if (variant == 2) hipLaunchKernelGGL(sp::k_pt<2>, grid, block, 0, st, a);
@@ -641,6 +716,8 @@ const char* sphip_kernel_name(int variant) {
 	return kVariantNames[variant];
 }
 
+int sphip_kernel_available(int variant) { return variant_built(variant) ? 1 : 0; }
+
 int sphip_plan_tile_rows(size_t height, int n_devices) {
 	if (height == 0 || n_devices < 1) return SPHIP_E_INVALID;
 	return plan_tile_rows(height, n_devices);
@@ -776,8 +853,8 @@ void sphip_destroy(sphip_t* c) {
 	}
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-	DevBuf* bufs[24] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
-	                     &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->bvh_sort, &c->bvh_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim, &c->cylm_rec, &c->cylm_cnt, &c->cylm_hdr };
+	DevBuf* bufs[] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
+	                   &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->sort_kv, &c->sort_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim, &c->cylm_rec, &c->cylm_hdr };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -910,6 +987,44 @@ int sphip_selftest_device(sphip_t* c, int what, const void* in, size_t n, void* 
 	(void)hipFree(d_in);
 	if (d_out) (void)hipFree(d_out);
 	if (e != hipSuccess) return fail(c, SPHIP_E_DEVICE, "selftest failed: %s", hipGetErrorString(e));
+	return SPHIP_OK;
+}
+
+int sphip_selftest_stage1(sphip_t* c, const float* rays, size_t n_rays, uint32_t* out_words, int32_t* out_order, uint32_t* tiles_out) {
+	if (!c) return SPHIP_E_INVALID;
+	if (!c->kids.empty()) return fail(c, SPHIP_E_STATE, "sphip_selftest_stage1 needs a single-device context (sphip_create)");
+	if (!c->have_scene) return fail(c, SPHIP_E_STATE, "sphip_selftest_stage1 called before a scene was set");
+	if (!tiles_out) return fail(c, SPHIP_E_INVALID, "tiles_out is NULL");
+	HIP_TRY(c, hipSetDevice(c->device));
+	hipStream_t st = c->own_stream;
+	int rc = ensure_cylm(c, st);
+	if (rc) return rc;
+	uint32_t hdr[8];
+	HIP_TRY(c, hipMemcpyAsync(hdr, c->cylm_hdr.p, sizeof hdr, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	const uint32_t tiles = hdr[6];
+	*tiles_out = tiles;
+	if (!out_words) return SPHIP_OK;
+	if (!rays || !out_order || n_rays == 0 || n_rays % 64 || n_rays > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad stage-1 selftest arguments (n_rays=%zu)", n_rays);
+	const size_t words_b = n_rays * tiles * 2 * sizeof(uint32_t), order_b = (size_t)tiles * sp::kMTile * sizeof(int32_t);
+	void *d_rays = nullptr, *d_words = nullptr, *d_order = nullptr;
+	hipError_t e = hipMalloc(&d_rays, n_rays * 24);
+	if (e == hipSuccess) e = hipMalloc(&d_words, words_b);
+	if (e == hipSuccess) e = hipMalloc(&d_order, order_b);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n_rays * 24, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) {
+		sp::CylStream cs{ (const float4*)c->cylm_rec.p, (const uint32_t*)c->cylm_hdr.p };
+		hipLaunchKernelGGL(sp::k_selftest_stage1, dim3((unsigned)(n_rays / 64)), dim3(64), 0, st, (const float*)d_rays, (uint32_t)n_rays, cs,
+		                   (const unsigned int*)c->bounds.p, (uint32_t*)d_words, (int*)d_order);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(out_words, d_words, words_b, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(out_order, d_order, order_b, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (d_rays) (void)hipFree(d_rays);
+	if (d_words) (void)hipFree(d_words);
+	if (d_order) (void)hipFree(d_order);
+	if (e != hipSuccess) return fail(c, SPHIP_E_DEVICE, "stage-1 selftest failed: %s", hipGetErrorString(e));
 	return SPHIP_OK;
 }
 

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "spath_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(sphip_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(sphip_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():
@@ -24,9 +24,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     L = capi.load()
-    assert L.sphip_abi_version() == 2
+    assert L.sphip_abi_version() == 3
     assert L.sphip_kernel_name(0) == b"auto" and L.sphip_kernel_name(99) is None
-    assert set(capi.kernel_variants()) >= {"auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4s", "rpl_cylm"}
+    names = capi.kernel_variants()
+    assert set(names) >= {"auto", "rpl_sload", "rpl_lds", "rpl_filter2", "rpl_cyl2s", "rpl_cyl4s", "rpl_cylw4s", "rpl_cylm"}
+    # what the shipped build carries: the exact-only scans, the opt-in BVH, one f32 filter scan for A/B runs, the default
+    have = set(capi.available_variants())
+    assert have >= {names["rpl_sload"], names["rpl_lds"], names["accel_lbvh"], names["rpl_cylw4s"], names["rpl_cylm"]}
+    assert L.sphip_kernel_available(0) == 0 and L.sphip_kernel_available(99) == 0
 
 
 def test_no_device_is_a_loud_error_not_a_fallback():

@@ -19,9 +19,13 @@ from spath_amd.dist import RowTilePlan, ShardedRenderer
 pytestmark = pytest.mark.gpu
 
 ACCUM_LINF_TOLERANCE = 0.0          # float accumulators: exact
-# rpl_sload, rpl_lds; slab-filter scans rpl_filter2/4/1/2s/4s; cylinder-filter scans rpl_cyl1/2/4/2s/4s (8 is the opt-in acceleration structure)
-VARIANTS = [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16]      # 14, 15: wave-shared stage 2; 16: stage 1 on the f16 matrix pipe
-TWO_STAGE = [3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16]
+# Every brute-force variant the loaded build carries (8 is the opt-in acceleration structure, tests/test_hip_accel.py).  The shipped
+# build: rpl_sload (1), rpl_lds (2), rpl_cylw4s (15: f32 cylinder filter, wave-shared stage 2), rpl_cylm (16: the default, stage 1 on
+# the f16 matrix pipe).  A -DSP_ALL_VARIANTS build (tools/pytest_with_lib.py) adds the slab-filter scans 3-7 and the per-lane
+# cylinder scans 9-14.
+VARIANTS = [v for v in capi.available_variants() if v != 8]
+TWO_STAGE = [v for v in VARIANTS if v >= 3]
+assert 16 in VARIANTS and 2 in VARIANTS
 
 
 def dev(a):
@@ -304,35 +308,42 @@ def test_leg_c_statistical_agreement_with_reference_stream(hip, O, scenes):
 
 
 def test_full_size_properties_config3(hip, O):
-    """BASELINE.json configs[2] shape (10k triangles, 1920x1080): properties that do not need the CPU oracle at
-    full size -- the exact scan and the filter scan agree bit for bit, idempotence, sharding invariance, scan
-    counts -- plus oracle spot checks on sampled pixels."""
+    """BASELINE.json configs[2] shape (10k triangles, 1920x1080), the SHIPPED DEFAULT (flags = 0) against the exact-only scan
+    (flags = 2, the reference's loop cpu_renderer.cpp:36-49 with nothing filtered) over the whole frame at 8 spp -- 8.3e11
+    ray-triangle pairs through both -- bit for bit; idempotence, sharding invariance, scan counts; oracle spot checks on
+    sampled pixels."""
     t, m = scene.closed_room(10000)
-    w, h = 1920, 1080
+    w, h, spp = 1920, 1080, 8
     rays = view.Camera(w, h).get_viewport()
     hip.set_scene(t, m)
     flat2 = hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=2)
     assert hip.stats()["scans_executed"] == w * h
-    flat3 = hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=3)
-    assert np.array_equal(flat2, flat3) and np.array_equal(flat3, hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=3))
+    flat0 = hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=0)
+    assert hip.stats()["kernel_variant"] == 16
+    assert np.array_equal(flat2, flat0) and np.array_equal(flat0, hip.render(rays, w, h, 1, mode=capi.MODE_FLAT, flags=0))
     assert (flat2[:, :3].sum(axis=1) > 0).all()                      # closed room: every primary ray hits
-    # path trace, 2 spp: 2e11 ray-triangle pairs through both scans
-    a_img, a_acc, a_st = render_pt(hip, rays, w, h, 2, 1, flags=2)
-    b_img, b_acc, b_st = render_pt(hip, rays, w, h, 2, 1, flags=3)
+    a_img, a_acc, a_st = render_pt(hip, rays, w, h, spp, 1, flags=2)
+    b_img, b_acc, b_st = render_pt(hip, rays, w, h, spp, 1, flags=0)
+    assert a_st["kernel_variant"] == 2 and b_st["kernel_variant"] == 16, (a_st, b_st)     # the library's own choice is what is compared
     assert np.array_equal(a_acc, b_acc) and np.array_equal(a_img, b_img)
     assert a_st["scans_executed"] == b_st["scans_executed"]
-    assert abs(a_st["scans_executed"] - w * h * 2 * 5) <= 1e-5 * w * h * 10      # closed scene: nominal == executed (edge leaks aside)
+    assert abs(a_st["scans_executed"] - w * h * spp * 5) <= 1e-5 * w * h * spp * 5      # closed scene: nominal == executed (edge leaks aside)
+    for v in [v for v in TWO_STAGE if v != 16]:                       # the other filter scans of this build, 2 spp each
+        c_img, c_acc, c_st = render_pt(hip, rays, w, h, 2, 1, flags=v)
+        d_img, d_acc, d_st = render_pt(hip, rays, w, h, 2, 1, flags=0)
+        assert c_st["kernel_variant"] == v and np.array_equal(c_acc, d_acc) and np.array_equal(c_img, d_img), v
     # oracle on a band of rows in the middle of the image (global pixel keys)
-    p0, n = 540 * w + 700, 512
-    want_img, want_acc, _ = O.render_counter(rays, t, m, 2, 1, pix0=p0, npix=n)
+    p0, n = 540 * w + 700, 256
+    want_img, want_acc, _ = O.render_counter(rays, t, m, spp, 1, pix0=p0, npix=n)
     assert np.array_equal(b_img[p0:p0 + n], want_img) and np.array_equal(b_acc[p0:p0 + n], want_acc)
-    # sharded over 8 'GPUs' == whole image
+    # sharded over 8 'GPUs' == whole image, with the default scan
     plan = RowTilePlan(w, h, 8, 8)
     st = torch.cuda.current_stream().cuda_stream
     parts = []
     for rank in range(8):
         sh = ShardedRenderer(hip, plan, rank, rays, torch.device("cuda"))
-        loc = sh.render(2, seed=1, flags=3, stream=st)
+        loc = sh.render(spp, seed=1, flags=0, stream=st)
+        assert hip.stats()["kernel_variant"] == 16
         buf = torch.zeros((plan.max_rays(), 4), dtype=torch.uint8, device="cuda"); buf[: sh.n] = loc
         parts.append(buf)
     torch.cuda.synchronize()
