@@ -328,18 +328,19 @@ def main():
     worst = None
     if world == 1 and NT >= 64 and not args.no_worst_case:
         # large triangles (clutter x10: most rays cross most cylinders): how far the two-stage scan degrades.  Untimed, after
-        # the timed region, with the 2-samples-per-lane instantiation so that the headline kernel's profile stays unmixed
+        # the timed region, with the same default kernel (a rocprofv3 pass of this command: --no-worst-case keeps the profile unmixed)
         wt, wm = scene.closed_room(NT, clutter_scale=10.0)
         d_wt, d_wm = torch.from_numpy(wt).to(dev), torch.from_numpy(wm).to(dev)
         ctx.set_scene_device(d_wt.data_ptr(), d_wm.data_ptr(), NT, stream)
         spp_w = min(SPP, 4)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        shard.render(spp_w, seed=1, mode=capi.MODE_PT, flags=variants["rpl_cyl2s"], stream=stream)
+        shard.render(spp_w, seed=1, mode=capi.MODE_PT, flags=flags, stream=stream)
         e1.record()
         torch.cuda.synchronize()
         sw = ctx.stats()
-        worst = {"scene": f"closed_room({NT}, clutter_scale=10): clutter triangles 10x larger", "kernel": "rpl_cyl2s", "spp": spp_w,
+        worst = {"scene": f"closed_room({NT}, clutter_scale=10): clutter triangles 10x larger",
+                 "kernel": capi.load().sphip_kernel_name(sw["kernel_variant"]).decode(), "spp": spp_w,
                  "kernel_ms": round(e0.elapsed_time(e1), 3), "Mray_per_s": round(W * H * spp_w * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2),
                  "tests_per_s": round(sw["scans_executed"] * NT / (e0.elapsed_time(e1) * 1e-3), 1),
                  "note": "no survivor queue, hence no overflow path: degrades smoothly towards the exact-only scan"}

@@ -197,9 +197,13 @@ int sphip_selftest_device(sphip_t* ctx, int what, const void* in, size_t n, void
  *   *tiles_out         256-triangle tiles of the scene's stream (call with out_words = NULL first to size the outputs)
  *   out_words[(k * tiles + t) * 2 + rb]   word of "lane" k (k = 64 b + l) for tile t: bit 31 - (4 f + j) set = the group of four
  *                      triangles 8 f + 2 j + (l >> 5) of tile t SURVIVES for ray 64 b + (l & 31) + 32 rb (f < 8, j < 4)
+ *   out_tri[((k * tiles + t) * 2 + rb) * 4 + f / 2]   (may be NULL) the same side products tested per TRIANGLE with the triangle's own
+ *                      cylinder radius (the per-pair form of the test): bit 31 - (16 (f & 1) + 4 j + i) set = triangle
+ *                      32 f + 8 j + 4 (l >> 5) + i of tile t survives for that ray.  Stronger than the group bit: a set triangle
+ *                      bit implies the set group bit
  *   out_order[t * 256 + 4 g + u]          index of the triangle at place u of group g of tile t (n_tris = padding)
  * Blocking; host pointers; single-device contexts. */
-int sphip_selftest_stage1(sphip_t* ctx, const float* rays, size_t n_rays, uint32_t* out_words, int32_t* out_order, uint32_t* tiles_out);
+int sphip_selftest_stage1(sphip_t* ctx, const float* rays, size_t n_rays, uint32_t* out_words, uint32_t* out_tri, int32_t* out_order, uint32_t* tiles_out);
 
 /* Blocks until the last render on this context has finished, then reports its figures. */
 int sphip_get_stats(sphip_t* ctx, sphip_stats* out);

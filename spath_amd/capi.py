@@ -113,7 +113,7 @@ def load():
         L.sphip_kernel_available.argtypes = [C.c_int]
     if hasattr(L, "sphip_selftest_stage1"):
         L.sphip_selftest_stage1.restype = C.c_int
-        L.sphip_selftest_stage1.argtypes = [vp, vp, sz, vp, vp, C.POINTER(C.c_uint32)]
+        L.sphip_selftest_stage1.argtypes = [vp, vp, sz, vp, vp, vp, C.POINTER(C.c_uint32)]
     L.sphip_create_multi.restype = C.c_int
     L.sphip_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.sphip_device_count.restype = C.c_int
@@ -280,10 +280,11 @@ class Context:
         self._check(self._L.sphip_selftest_device(self._h, what, inp.ctypes.data, n, out.ctypes.data), "sphip_selftest_device")
         return out
 
-    def selftest_stage1(self, rays):
+    def selftest_stage1(self, rays, per_triangle=True):
         """sphip_selftest_stage1 (test-only): stage 1 of the default scan alone for the given rays (padded to a multiple of 64)
-        against the context's scene.  Returns (survive, order): survive[ray, stream position] (bool: the position's group of
-        four triangles survives stage 1 for that ray) and order[stream position] = triangle index (n_tris = padding)."""
+        against the context's scene.  Returns (group_survives, tri_survives, order): both [ray, stream position] bool -- the
+        position's group of four survives the grouped bound / the triangle itself survives the per-pair form of the test
+        (None unless per_triangle) -- and order[stream position] = triangle index (n_tris = padding)."""
         import numpy as np
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         n = rays.shape[0]
@@ -291,23 +292,38 @@ class Context:
         if n_pad != n:
             rays = np.concatenate([rays, np.repeat(rays[-1:], n_pad - n, axis=0)])
         tiles = C.c_uint32(0)
-        self._check(self._L.sphip_selftest_stage1(self._h, None, 0, None, None, C.byref(tiles)), "sphip_selftest_stage1")
+        self._check(self._L.sphip_selftest_stage1(self._h, None, 0, None, None, None, C.byref(tiles)), "sphip_selftest_stage1")
         t = tiles.value
         words = np.zeros(n_pad * t * 2, dtype=np.uint32)
+        tri = np.zeros(n_pad * t * 8, dtype=np.uint32) if per_triangle else None
         order = np.zeros(t * 256, dtype=np.int32)
-        self._check(self._L.sphip_selftest_stage1(self._h, rays.ctypes.data, n_pad, words.ctypes.data, order.ctypes.data, C.byref(tiles)),
-                    "sphip_selftest_stage1")
+        self._check(self._L.sphip_selftest_stage1(self._h, rays.ctypes.data, n_pad, words.ctypes.data, tri.ctypes.data if per_triangle else None,
+                                                  order.ctypes.data, C.byref(tiles)), "sphip_selftest_stage1")
+        nb = n_pad // 64
         # words[(64 b + l), tile, rb]: bit 31 - (4 f + j) <-> group 8 f + 2 j + (l >> 5), ray 64 b + (l & 31) + 32 rb
-        w = words.reshape(n_pad // 64, 2, 32, t, 2)                      # [block, half, column, tile, rb]
+        w = words.reshape(nb, 2, 32, t, 2)                               # [block, half, column, tile, rb]
         bits = ((w[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)     # [..., k = 4 f + j]
         k = np.arange(32)
-        surv = np.zeros((n_pad // 64, 64, t, 64), dtype=bool)            # [block, ray in block, tile, group]
+        surv = np.zeros((nb, 64, t, 64), dtype=bool)                     # [block, ray in block, tile, group]
         for hh in range(2):
             grp = 8 * (k // 4) + 2 * (k % 4) + hh
             for rb in range(2):
-                surv[:, 32 * rb:32 * rb + 32][:, :, :, grp] = bits[:, hh, :, :, rb, :]
+                surv[:, 32 * rb:32 * rb + 32, :, grp] = bits[:, hh, :, :, rb, :]
         surv = np.repeat(surv.reshape(n_pad, t * 64), 4, axis=1)         # per stream position
-        return surv[:n], order
+        tsurv = None
+        if per_triangle:
+            # tri[(64 b + l), tile, rb, q]: bit 31 - (16 (f & 1) + 4 j + i), f = 2 q + (bit >= 16) <-> triangle 32 f + 8 j + 4 (l >> 5) + i
+            tw = tri.reshape(nb, 2, 32, t, 2, 4)
+            tb = ((tw[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)   # [block, half, column, tile, rb, q, bit]
+            tsurv = np.zeros((nb, 64, t, 256), dtype=bool)
+            q, bit = np.meshgrid(np.arange(4), np.arange(32), indexing="ij")
+            f, j, i = 2 * q + bit // 16, (bit % 16) // 4, bit % 4
+            for hh in range(2):
+                pos = (32 * f + 8 * j + 4 * hh + i).reshape(-1)
+                for rb in range(2):
+                    tsurv[:, 32 * rb:32 * rb + 32, :, pos] = tb[:, hh, :, :, rb].reshape(nb, 32, t, 128)
+            tsurv = tsurv.reshape(n_pad, t * 256)[:n]
+        return surv[:n], tsurv, order
 
     def stats(self) -> dict:
         s = Stats()

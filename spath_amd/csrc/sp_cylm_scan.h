@@ -43,6 +43,8 @@
 #include "sp_cyl_scan.h"
 #include "sp_radix_sort.h"
 
+#include <type_traits>
+
 namespace sp {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -221,6 +223,36 @@ __global__ void __launch_bounds__(64) k_selftest_cylm(const float* __restrict__ 
 	}
 }
 
+// the stream's class table in scalar registers, read ONCE per scan: inside the tile loop a read of cs.hdr is a vector-memory load with
+// an s_waitcnt vmcnt(0) behind it -- a round trip to L2 per tile, and a wait for the LDS-DMA in flight as well (vmcnt counts in order)
+struct CylmHdr {
+	uint32_t n0, n1, n2, f1, f2, tiles;      // triangles per class; first tile of classes 1 and 2 (class 0 starts at tile 0); tiles in all
+	float S;
+	// the class being scanned (scalars on purpose: an array indexed by the class number ends up in scratch memory, and a scratch
+	// load waits on vmcnt like any other)
+	uint32_t cls, cn, cfirst, cend;
+	SP_DEV void load(const uint32_t* __restrict__ hdr) {
+		n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[0]); n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[1]);
+		n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[2]);
+		f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[4]); f2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[5]);
+		tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[6]);
+		S = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[7]));
+		cls = 0u; cn = n0; cfirst = 0u; cend = f1;
+	}
+	// tile gt lies beyond the current class: move on (true), at most twice per tile (an empty class 1)
+	SP_DEV bool next_class(uint32_t gt) {
+		if (cls >= 2u || gt < cend) return false;
+		++cls;
+		if (cls == 1u) { cn = n1; cfirst = f1; cend = f2; } else { cn = n2; cfirst = f2; cend = tiles; }
+		return true;
+	}
+	// triangles of the current class in its tile gt, as fragments of 32
+	SP_DEV uint32_t fragments(uint32_t gt) const {
+		const uint32_t left = cn - (gt - cfirst) * kMTile;
+		return ((left < kMTile ? left : kMTile) + 31u) / 32u;
+	}
+};
+
 // ---- ray side of stage 1.  The lane's own ray: the f32 filter state of cyl_setup (stage 2 recomputes x in f32) and its scaled
 // values; per class the B fragments, D^ and Dq^ of the wave's two ray blocks (lane l: column l & 31 of block rb, K half l >> 5)
 struct CylmRay {
@@ -327,57 +359,168 @@ SP_DEV void cylm_fragment(const float4* cur, uint32_t tb, uint32_t lane, const C
 	}
 }
 
-constexpr uint32_t kMCap = 512u;             // list entries per wave and pass (16 bits each: ray << 6 | group)
+// the VALU half of cylm_fragment for one ray block: 4 group bits from the 16 side products g and the four Hmax of the lane half
+SP_DEV uint32_t cylm_bits(const float16v& g, const float4 Hm, float Dn, float Dqn, uint32_t word) {
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const float hm = j == 0 ? Hm.x : j == 1 ? Hm.y : j == 2 ? Hm.z : Hm.w;
+		const float m = min4_abs(g[4 * j + 0], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+		const float x = __builtin_fmaf(-hm, Dn, m);
+		word = __builtin_amdgcn_alignbit(word, __float_as_uint(x - Dqn), 31);
+	}
+	return word;
+}
+
+// ---- stage 1 of a whole tile (nblk fragments), software-pipelined by hand: the matrix instruction of the NEXT (fragment, ray
+// block) is issued before the 20 VALU instructions that turn the previous result into bits, and the LDS reads run a fragment
+// ahead -- an in-order wave otherwise sits through the LDS latency, both matrix instructions and their result latency before its
+// first VALU instruction of every fragment.  No extra accumulators: a ray block's 16 registers are free again when its bits are out.
+SP_DEV void cylm_stage1(const float4* cur, uint32_t nblk, uint32_t lane, const CylmRay& R, uint32_t (&word)[2]) {
+	if (nblk == 0u) return;
+	const half8* frags = (const half8*)(cur + kMRecQ) + lane;
+	const float4* hmq = cur + cylm_hmq(0u, lane >> 5);
+	float16v zero;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+	half8 afr = frags[0];
+	float4 Hm = hmq[0];
+	float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[0], zero, 0, 0, 0);
+	float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[1], zero, 0, 0, 0);
+	for (uint32_t tb = 1; tb < nblk; ++tb) {
+		const half8 afr_n = frags[tb * 64u];
+		const float4 Hm_n = hmq[tb * 2u];
+		__builtin_amdgcn_sched_barrier(0);
+		word[0] = cylm_bits(g0, Hm, R.Dn[0], R.Dqn[0], word[0]);
+		__builtin_amdgcn_sched_barrier(0);
+		g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_n, R.bfr[0], zero, 0, 0, 0);
+		__builtin_amdgcn_sched_barrier(0);
+		word[1] = cylm_bits(g1, Hm, R.Dn[1], R.Dqn[1], word[1]);
+		__builtin_amdgcn_sched_barrier(0);
+		g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_n, R.bfr[1], zero, 0, 0, 0);
+		Hm = Hm_n;
+	}
+	word[0] = cylm_bits(g0, Hm, R.Dn[0], R.Dqn[0], word[0]);
+	word[1] = cylm_bits(g1, Hm, R.Dn[1], R.Dqn[1], word[1]);
+}
+
+constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: ray << 6 | group); what does not fit waits for the next pass
+constexpr uint32_t kMQ2 = 128u;              // exact-test candidates a wave can hold (32 bits each: ray << 26 | triangle index)
+constexpr uint32_t kMIdxBits = 26u;          // hence at most 2^26 - 1 triangles for this scan (the host picks another one beyond)
+
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then the row
+// totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six v_add_u32_dpp, no LDS.  Full waves only.
+SP_DEV uint32_t wave_incl_scan(uint32_t x) {
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
 
 // Closest hit for the ray of every lane.  Block-uniform call (barriers inside).
+//
+// Stage 2 in two steps, both shared by the whole wave:
+//   (a) per tile: the set group bits become a list of (ray, group) entries (list space by a wave prefix sum); 64 entries per round,
+//       one per lane: the f32 cylinder test of sp_cyl_scan.h on the group's four records, each with its own H -> candidates;
+//   (b) the candidates (ray, triangle index) go to a per-wave stack that OUTLIVES the tile -- the exact test reads the
+//       exact record from L2 and the ray from the donor lane's registers, nothing of the tile -- and ray_tri_strict runs only on
+//       full batches of 64 (and on what is left at the end of the scan): every lane busy in every exact turn, where one turn
+//       per round and its stragglers' turns used half of them (profiles/filter_stats.json).
+// Results meet in the 64-bit LDS atomicMin on (d, index) keys, so no order matters (sp_cyl_scan.h, scan_cylw).
 SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlots<1>& s, float (&bd)[1], int (&bi)[1]) {
-	__shared__ float4 sm[2 * kMTileQ];
+	// Two tile buffers as two separate LDS objects, the tile loop unrolled over them: the LDS-DMA of the next tile is issued BEFORE
+	// stage 1 of the current one, and hipcc, which orders every LDS read it cannot tell apart from an outstanding LDS-DMA behind
+	// s_waitcnt vmcnt(0), can tell these apart -- the transfer has the whole tile to land in, not just stage 2
+	__shared__ float4 sm0[kMTileQ];
+	__shared__ float4 sm1[kMTileQ];
 	__shared__ unsigned short lst[4 * kMCap];
-	__shared__ uint32_t lcnt[4];
+	__shared__ uint32_t q2[4 * kMQ2];
 	__shared__ unsigned long long cell[256];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u, hh = lane >> 5;
 	unsigned short* const mylst = lst + (tid >> 6) * kMCap;
-	uint32_t* const mycnt = lcnt + (tid >> 6);
-	const float S = ((const float*)cs.hdr)[7];
+	uint32_t* const myq2 = q2 + (tid >> 6) * kMQ2;
+	CylmHdr hd;
+	hd.load(cs.hdr);
 
 	CylmRay R;
-	R.setup(rv, S, s);
+	R.setup(rv, hd.S, s);
 	CylRay<1>& f = R.f;
 
 	const unsigned long long kNone = ((unsigned long long)__float_as_uint(kMaxDist) << 32) | 0xffffffffull;
 	cell[tid] = kNone;
 	R.build(0u, lane);
 
-	const uint32_t total_tiles = cs.hdr[6];
-	uint32_t cls = 0;
+	// ---- step (b): exact tests of the top n (<= 64) candidates of the stack; wave-uniform n
+	uint32_t q2n = 0;                                     // candidates on the stack (wave-uniform)
+	auto exact_batch = [&](uint32_t n) {
+		const bool ok = lane < n;
+		// idle lanes (only in the last batch of a scan): their own ray against the zero record behind the last triangle
+		const uint32_t e = ok ? myq2[q2n - n + lane] : ((lane << kMIdxBits) | a.n_tris);
+		const int L = (int)(e >> kMIdxBits);
+		const int idx = (int)(e & ((1u << kMIdxBits) - 1u));
+		const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
+		const float ox = __shfl(s.o[0].x, L, 64), oy = __shfl(s.o[0].y, L, 64), oz = __shfl(s.o[0].z, L, 64);
+		const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
+		const int src = __shfl(s.src[0], L, 64);
+		const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+		// cpu_renderer.cpp:44: cur_d > 0 && cur_d < d, d starting at MAX_VALUE_DIST; ties -> lowest index: the key's low word
+		if (ok && (d > 0.0f) && (d < kMaxDist) && (idx != src))
+			atomicMin(&cell[(int)wbase + L], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)idx);
+		q2n -= n;
+#ifdef SP_FILTER_STATS
+		if (lane == 0) { atomicAdd(a.scans + 5, 1ull); atomicAdd(a.scans + 4, (unsigned long long)n); }
+#endif
+	};
+
+	const uint32_t total_tiles = hd.tiles;
 #ifdef SP_EXP_NO_STAGE2
 	uint32_t exp_acc = 0;
 #endif
-	__syncthreads();                                  // readers of the previous scan are done with sm
-	cylm_tile_dma(cs.rec, sm, tid, wbase);
+#ifdef SP_PHASE_TIMERS          // diagnostic build only (tools/phase_timers.py): wave lifetime by phase, in shader cycles -> a.scans[8..13]
+	unsigned long long ph_s1 = 0, ph_list = 0, ph_retest = 0, ph_exact = 0, ph_bar = 0, ph_t0 = 0, ph_t1 = 0;
+#define SP_PH_STAMP(v) v = __builtin_amdgcn_s_memtime()
+#define SP_PH_ADD(acc, a_, b_) acc += (b_) - (a_)
+#else
+#define SP_PH_STAMP(v)
+#define SP_PH_ADD(acc, a_, b_)
+#endif
+	__syncthreads();                                  // readers of the previous scan are done with the buffers
+	cylm_tile_dma(cs.rec, sm0, tid, wbase);
 	__syncthreads();
-	for (uint32_t gt = 0; gt < total_tiles; ++gt) {
-		while (cls < 2u && gt >= cs.hdr[4 + cls]) {
-			++cls;
+	auto tile_body = [&](auto parity, const uint32_t gt) {
+		const float4* const cur = decltype(parity)::value ? sm1 : sm0;
+		float4* const nxt = decltype(parity)::value ? sm0 : sm1;
+#ifndef SP_CYLM_LATE_DMA
+		// the next tile streams in from here on (its buffer was released by the barrier that ended the previous tile)
+		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, nxt, tid, wbase);
+#endif
+		SP_PH_STAMP(ph_t0);
+		while (hd.next_class(gt)) {
 			// f32 state of stage 2 rotates as in scan_cylw; the halves are rebuilt for the class
 			const float t0 = f.Pa[0]; f.Pa[0] = f.Pb[0]; f.Pb[0] = f.Pc[0]; f.Pc[0] = t0;
-			R.build(cls, lane);
+			R.build(hd.cls, lane);
 		}
-		const float4* cur = sm + (gt & 1u) * kMTileQ;
-		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kMTile;
-		const uint32_t nblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kMTile ? left : kMTile) + 31u) / 32u));
+		const uint32_t nblk = hd.fragments(gt);
 		// ---- stage 1: word[rb] gets 4 bits per fragment (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
 		uint32_t word[2] = { 0u, 0u };
+#ifdef SP_CYLM_NO_PIPELINE
 		for (uint32_t tb = 0; tb < nblk; ++tb) cylm_fragment(cur, tb, lane, R, word);
+#else
+		cylm_stage1(cur, nblk, lane, R, word);
+#endif
 		const uint32_t done = nblk * 4u;                              // bits appended; left-align
 #pragma unroll
 		for (int rb = 0; rb < 2; ++rb) word[rb] = done == 0u ? 0u : (word[rb] << (32u - done));
 #ifdef SP_DBG_ALLBITS
 		word[0] = word[1] = done == 0u ? 0u : (0xffffffffu << (32u - done));
 #endif
-		// the next tile streams in while the survivors are resolved
-		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, sm + ((gt + 1u) & 1u) * kMTileQ, tid, wbase);
-		// ---- stage 2: one list per wave; entry = (ray = donor lane) << 6 | group
+		SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_s1, ph_t0, ph_t1);
+#ifdef SP_CYLM_LATE_DMA
+		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, nxt, tid, wbase);
+#endif
+		// ---- stage 2 (a): one list per wave; entry = (ray = donor lane) << 6 | group
 #ifdef SP_EXP_NO_STAGE2
 		exp_acc ^= word[0] ^ word[1];
 		for (; false;) {
@@ -385,11 +528,11 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		for (;;) {
 #endif
 			const uint32_t c = (uint32_t)__builtin_popcount(word[0]) + (uint32_t)__builtin_popcount(word[1]);
-			if (!__any(c != 0u)) break;
-			if (lane == 0) *mycnt = 0u;
-			__builtin_amdgcn_wave_barrier();                             // the reset is issued before any lane's add (one wave: LDS operations stay in order)
-			uint32_t j = c ? atomicAdd(mycnt, c) : 0u;
-			const uint32_t jend = j + c < kMCap ? j + c : kMCap;
+			const uint32_t incl = wave_incl_scan(c);
+			const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			if (all == 0u) break;
+			uint32_t j = incl - c;
+			const uint32_t jend = incl < kMCap ? incl : kMCap;            // what does not fit stays in the words for the next pass
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb) {
 				uint32_t m = word[rb];
@@ -403,20 +546,18 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				}
 				word[rb] = m;
 			}
-			__builtin_amdgcn_wave_barrier();                             // every lane's entries are issued before the list is read back
-			uint32_t total = *mycnt;
-			total = (uint32_t)__builtin_amdgcn_readfirstlane((int)(total < kMCap ? total : kMCap));
+			__builtin_amdgcn_wave_barrier();                             // every lane's entries are issued before the list is read back (one wave: LDS operations complete in order)
+			const uint32_t total = all < kMCap ? all : kMCap;
 #ifdef SP_FILTER_STATS
 			if (lane == 0) { atomicAdd(a.scans + 1, (unsigned long long)total); atomicAdd(a.scans + 2, (unsigned long long)((total + 63u) / 64u)); }
 #endif
+			SP_PH_STAMP(ph_t0); SP_PH_ADD(ph_list, ph_t1, ph_t0);
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t ent = base + lane;
 				const bool ok = ent < total;
 				const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 6);
 				const int L = (int)(entry >> 6);
 				const uint32_t grp = entry & 63u;
-				const float ox = __shfl(s.o[0].x, L, 64), oy = __shfl(s.o[0].y, L, 64), oz = __shfl(s.o[0].z, L, 64);
-				const int src = __shfl(s.src[0], L, 64);
 				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
 				const float Pa = __shfl(f.Pa[0], L, 64), Pb = __shfl(f.Pb[0], L, 64), Pc = __shfl(f.Pc[0], L, 64);
 				const float D = __shfl(f.D[0], L, 64), Dq = __shfl(f.Dq[0], L, 64);
@@ -424,7 +565,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				uint32_t cand = 0;
 				const CylmGroup G = cylm_group(cur, grp);
 				const float4 gi = cur[cylm_slot(grp, 6u)];
-				const int idx4[4] = { (int)__float_as_uint(gi.x), (int)__float_as_uint(gi.y), (int)__float_as_uint(gi.z), (int)__float_as_uint(gi.w) };
+				const uint32_t idx4[4] = { __float_as_uint(gi.x), __float_as_uint(gi.y), __float_as_uint(gi.z), __float_as_uint(gi.w) };
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const float mz = u == 0 ? G.mh01.x : u == 1 ? G.mh01.z : u == 2 ? G.mh23.x : G.mh23.z;
@@ -432,33 +573,47 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 					const float x = cyl_x(G.q0[u], mz, Hh, Pa, Pb, Pc, -dx, -dy, -dz, D);
 					cand |= (ok && !(x - Dq >= 0.0f)) ? (1u << u) : 0u;
 				}
-				while (__any(cand != 0u)) {
-#ifdef SP_FILTER_STATS
-					if (lane == 0) atomicAdd(a.scans + 5, 1ull);
-#endif
-					if (cand != 0u) {
-						const uint32_t low = cand & (0u - cand);
-						cand ^= low;
-						const int idx = (low & 1u) ? idx4[0] : (low & 2u) ? idx4[1] : (low & 4u) ? idx4[2] : idx4[3];
-#ifdef SP_FILTER_STATS
-						atomicAdd(a.scans + 4, 1ull);
-#endif
-						const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
-						const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
-						if ((d > 0.0f) && (d < kMaxDist) && (idx != src))
-							atomicMin(&cell[(int)wbase + L], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)idx);
-					}
+				SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_retest, ph_t0, ph_t1);
+				// ---- (b): the candidates go on the wave's stack; a full batch of 64 is tested as soon as the next ones would not fit
+#pragma unroll 1
+				for (int u = 0; u < 4; ++u) {                                // (not unrolled: one copy of the batch code)
+					const bool mine = (cand >> u) & 1u;
+					const unsigned long long mk = __ballot(mine);
+					const uint32_t cnt = (uint32_t)__popcll(mk);
+					if (q2n + cnt > kMQ2) exact_batch(64u);                  // q2n > kMQ2 - 64 >= 64 here
+					const uint32_t idx = u == 0 ? idx4[0] : u == 1 ? idx4[1] : u == 2 ? idx4[2] : idx4[3];
+					if (mine) myq2[q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = ((uint32_t)L << kMIdxBits) | idx;
+					q2n += cnt;
 				}
+				__builtin_amdgcn_wave_barrier();
+				SP_PH_STAMP(ph_t0); SP_PH_ADD(ph_exact, ph_t1, ph_t0);
 			}
+			SP_PH_STAMP(ph_t1);
 		}
+		// full batches now rather than later: the exact turns overlap the arrival of the next tile
+		while (q2n >= 64u) exact_batch(64u);
 #ifdef SP_FILTER_STATS
 		if (lane == 0) atomicAdd(a.scans + 3, 1ull);
 #endif
+		SP_PH_STAMP(ph_t0); SP_PH_ADD(ph_list, ph_t1, ph_t0);
 		__syncthreads();                        // next tile landed (vmcnt(0) in the fence) and this one is free again
+		SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_bar, ph_t0, ph_t1);
+	};
+	for (uint32_t gt = 0; gt < total_tiles; gt += 2u) {
+		tile_body(std::integral_constant<int, 0>{}, gt);
+		if (gt + 1u < total_tiles) tile_body(std::integral_constant<int, 1>{}, gt + 1u);
 	}
+	if (q2n) exact_batch(q2n);                  // (q2n < 64 here)
+#ifdef SP_PHASE_TIMERS
+	if (lane == 0) {
+		atomicAdd(a.scans + 8, ph_s1); atomicAdd(a.scans + 9, ph_list); atomicAdd(a.scans + 10, ph_retest); atomicAdd(a.scans + 11, ph_exact);
+		atomicAdd(a.scans + 12, ph_bar); atomicAdd(a.scans + 13, 1ull);
+	}
+#endif
 #ifdef SP_EXP_NO_STAGE2
 	if (exp_acc == 0x12345678u) cell[tid] = 0ull;
 #endif
+	__builtin_amdgcn_wave_barrier();
 	const unsigned long long k = cell[tid];
 	bd[0] = __uint_as_float((uint32_t)(k >> 32));
 	bi[0] = (int)(uint32_t)k;
@@ -467,34 +622,69 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 // ---- test-only (sphip_selftest_stage1): stage 1 ALONE, exactly as scan_cylm runs it (same ray setup, same fragment function,
 // same tiles), for 64 rays per one-wave workgroup (n_rays a multiple of 64).  out_words[((block * 64 + lane) * tiles + tile) * 2 + rb] = the lane's word:
 // bit 31 - (4 tb + j) = group 8 tb + 2 j + (lane >> 5) of that tile survives for ray 64 block + (lane & 31) + 32 rb.
+// out_tri (optional): the same side products g tested PER TRIANGLE with the triangle's own scaled H (x = fma(-H^, D^, |g|), sign(x - Dq^)):
+// out_tri[(((block * 64 + lane) * tiles + tile) * 2 + rb) * 4 + tb / 2], bit 31 - (16 (tb & 1) + 4 j + i) = triangle 32 tb + 8 j + 4 (lane >> 5) + i.
+// A group bit may be set where none of its triangle bits is (the group bound is weaker), never the other way round.
 // Block 0 also writes the stream order: out_order[tile * kMTile + 4 group + u] = triangle index at that place (n_tris = padding).
 __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict__ rays, uint32_t n_rays, const CylStream cs, const unsigned int* __restrict__ bounds,
-                                                      uint32_t* __restrict__ out_words, int* __restrict__ out_order) {
+                                                      uint32_t* __restrict__ out_words, uint32_t* __restrict__ out_tri, int* __restrict__ out_order) {
 	__shared__ float4 sm[kMTileQ];
-	const uint32_t lane = threadIdx.x;
+	const uint32_t lane = threadIdx.x, hh = lane >> 5;
 	const float rv = __uint_as_float(bounds[0]);
-	const float S = ((const float*)cs.hdr)[7];
+	CylmHdr hd;
+	hd.load(cs.hdr);
 	const uint32_t k = blockIdx.x * 64u + lane, kk = k < n_rays ? k : n_rays - 1u;
 	RaySlots<1> s;
 	const float* p = rays + (size_t)kk * 6;
 	s.o[0] = mk3(p[0], p[1], p[2]); s.dir[0] = mk3(p[3], p[4], p[5]); s.src[0] = -1; s.act[0] = true;
 	CylmRay R;
-	R.setup(rv, S, s);
+	R.setup(rv, hd.S, s);
 	R.build(0u, lane);
-	const uint32_t total_tiles = cs.hdr[6];
-	uint32_t cls = 0;
+	const float kH = hd.S > 0.0f ? 256.0f / hd.S : 1.0f;
+	const uint32_t total_tiles = hd.tiles;
 	for (uint32_t gt = 0; gt < total_tiles; ++gt) {
-		while (cls < 2u && gt >= cs.hdr[4 + cls]) { ++cls; R.build(cls, lane); }
+		while (hd.next_class(gt)) R.build(hd.cls, lane);
 		__syncthreads();
 		for (uint32_t q = lane; q < kMTileQ; q += 64u) sm[q] = cs.rec[(size_t)gt * kMTileQ + q];
 		__syncthreads();
-		const uint32_t left = cs.hdr[cls] - (gt - cs.hdr[3 + cls]) * kMTile;
-		const uint32_t nblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((left < kMTile ? left : kMTile) + 31u) / 32u));
+		const uint32_t nblk = hd.fragments(gt);
 		uint32_t word[2] = { 0u, 0u };
-		for (uint32_t tb = 0; tb < nblk; ++tb) cylm_fragment(sm, tb, lane, R, word);
+		cylm_stage1(sm, nblk, lane, R, word);
 		const uint32_t done = nblk * 4u;
 #pragma unroll
 		for (int rb = 0; rb < 2; ++rb) if (k < n_rays) out_words[((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb] = done == 0u ? 0u : (word[rb] << (32u - done));
+		if (out_tri) {
+			float16v zero;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+			for (uint32_t tb = 0; tb < kMBlocks; ++tb) {
+				const half8 afr = ((const half8*)(sm + kMRecQ))[tb * 64u + lane];
+				const float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[0], zero, 0, 0, 0);
+				const float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[1], zero, 0, 0, 0);
+#pragma unroll
+				for (int rb = 0; rb < 2; ++rb) {
+					const float16v& g = rb == 0 ? g0 : g1;
+					uint32_t w = 0;
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const uint32_t grp = tb * 8u + 2u * (uint32_t)j + hh;
+						const float4 a = sm[cylm_slot(grp, 4u)], b = sm[cylm_slot(grp, 5u)];
+						const float H4[4] = { a.y * kH, a.w * kH, b.y * kH, b.w * kH };
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const float x = __builtin_fmaf(-H4[i], R.Dn[rb], __builtin_fabsf(g[4 * j + i]));
+							w = __builtin_amdgcn_alignbit(w, __float_as_uint(x - R.Dqn[rb]), 31);
+						}
+					}
+					// two fragments per output word: even fragment in the high half
+					if (k < n_rays) {
+						uint32_t* o = out_tri + (((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb) * 4u + (tb >> 1);
+						if (tb >= nblk) w = 0u;
+						if ((tb & 1u) == 0u) *o = w << 16; else *o |= (w & 0xffffu);
+					}
+				}
+			}
+		}
 		if (blockIdx.x == 0) {
 			const float4 gi = sm[cylm_slot(lane, 6u)];
 			int* o = out_order + (size_t)gt * kMTile + 4u * lane;

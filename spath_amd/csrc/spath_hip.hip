@@ -126,6 +126,7 @@ int pick_variant(int flags, size_t n_tris) {
 	const int v = flags & SPHIP_KERNEL_MASK;
 	if (v >= 1 && v <= kVariantLast) return v;
 	if (n_tris < 64) return 1;        // tiny scenes: nothing to filter, the scalar path has no barriers
+	if (n_tris >= (1ull << sp::kMIdxBits)) return 15;      // the default scan packs (ray, triangle index) into 32 bits: 6 + 26
 	// The third-generation scan (sp_cylm_scan.h: stage 1 on the f16 matrix pipe, one ray per lane) for every mode; sample chunks
 	// (launch_render) supply the workgroups a small frame lacks.
 	return 16;
@@ -265,7 +266,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	if (mode == kModeHits && !d_accum) return fail(c, SPHIP_E_INVALID, "null distance output");
 	if (mode == SPHIP_MODE_PT && (n_samples == 0 || n_samples > 0x7fffffffull))
 		return fail(c, SPHIP_E_INVALID, "n_samples must be in [1, 2^31) (the reference divides by it, cpu_renderer.cpp:77)");
-	int rc = ensure(c, c->counter, 8 * sizeof(unsigned long long));
+	int rc = ensure(c, c->counter, 16 * sizeof(unsigned long long));
 	if (rc) return rc;
 
 	sp::KArgs a{};
@@ -290,9 +291,11 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	a.inv_n = (float)(1.0 / (double)(n_samples ? n_samples : 1));      // cpu_renderer.cpp:77
 
 	const int variant = pick_variant(flags, c->n_tris);
+	if (variant == 16 && c->n_tris >= (1ull << sp::kMIdxBits))
+		return fail(c, SPHIP_E_INVALID, "rpl_cylm handles scenes of fewer than 2^%u triangles (this one has %zu); use rpl_cylw4s", sp::kMIdxBits, c->n_tris);
 	if (!variant_built(variant))
 		return fail(c, SPHIP_E_INVALID, "kernel variant %d (%s) is not compiled into this build of libspath_hip (rebuild with -DSP_ALL_VARIANTS)", variant, kVariantNames[variant]);
-	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, 8 * sizeof(unsigned long long), st));
+	HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, 16 * sizeof(unsigned long long), st));
 	// sample chunks: the filter kernels keep 1024 workgroups resident (256 CUs x 4); a launch of only a few times that
 	// many ends with a long tail (its time is that of the slowest workgroup, ~12 % above the mean when everything starts
 	// together), so small frames and multi-GPU shards are split along the samples as well
@@ -990,7 +993,7 @@ int sphip_selftest_device(sphip_t* c, int what, const void* in, size_t n, void* 
 	return SPHIP_OK;
 }
 
-int sphip_selftest_stage1(sphip_t* c, const float* rays, size_t n_rays, uint32_t* out_words, int32_t* out_order, uint32_t* tiles_out) {
+int sphip_selftest_stage1(sphip_t* c, const float* rays, size_t n_rays, uint32_t* out_words, uint32_t* out_tri, int32_t* out_order, uint32_t* tiles_out) {
 	if (!c) return SPHIP_E_INVALID;
 	if (!c->kids.empty()) return fail(c, SPHIP_E_STATE, "sphip_selftest_stage1 needs a single-device context (sphip_create)");
 	if (!c->have_scene) return fail(c, SPHIP_E_STATE, "sphip_selftest_stage1 called before a scene was set");
@@ -1007,23 +1010,26 @@ int sphip_selftest_stage1(sphip_t* c, const float* rays, size_t n_rays, uint32_t
 	if (!out_words) return SPHIP_OK;
 	if (!rays || !out_order || n_rays == 0 || n_rays % 64 || n_rays > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad stage-1 selftest arguments (n_rays=%zu)", n_rays);
 	const size_t words_b = n_rays * tiles * 2 * sizeof(uint32_t), order_b = (size_t)tiles * sp::kMTile * sizeof(int32_t);
-	void *d_rays = nullptr, *d_words = nullptr, *d_order = nullptr;
+	void *d_rays = nullptr, *d_words = nullptr, *d_order = nullptr, *d_tri = nullptr;
 	hipError_t e = hipMalloc(&d_rays, n_rays * 24);
 	if (e == hipSuccess) e = hipMalloc(&d_words, words_b);
+	if (e == hipSuccess && out_tri) e = hipMalloc(&d_tri, words_b * 4);
 	if (e == hipSuccess) e = hipMalloc(&d_order, order_b);
 	if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n_rays * 24, hipMemcpyHostToDevice, st);
 	if (e == hipSuccess) {
 		sp::CylStream cs{ (const float4*)c->cylm_rec.p, (const uint32_t*)c->cylm_hdr.p };
 		hipLaunchKernelGGL(sp::k_selftest_stage1, dim3((unsigned)(n_rays / 64)), dim3(64), 0, st, (const float*)d_rays, (uint32_t)n_rays, cs,
-		                   (const unsigned int*)c->bounds.p, (uint32_t*)d_words, (int*)d_order);
+		                   (const unsigned int*)c->bounds.p, (uint32_t*)d_words, (uint32_t*)d_tri, (int*)d_order);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(out_words, d_words, words_b, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipMemcpyAsync(out_order, d_order, order_b, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && out_tri) e = hipMemcpyAsync(out_tri, d_tri, words_b * 4, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (d_rays) (void)hipFree(d_rays);
 	if (d_words) (void)hipFree(d_words);
 	if (d_order) (void)hipFree(d_order);
+	if (d_tri) (void)hipFree(d_tri);
 	if (e != hipSuccess) return fail(c, SPHIP_E_DEVICE, "stage-1 selftest failed: %s", hipGetErrorString(e));
 	return SPHIP_OK;
 }
@@ -1049,6 +1055,15 @@ int sphip_get_stats(sphip_t* c, sphip_stats* out) {
 		unsigned long long x[3] = {0, 0, 0};
 		(void)hipMemcpy(x, c->counter.p, sizeof x, hipMemcpyDeviceToHost);
 		fprintf(stderr, "[bvh stats] scans=%llu steps/scan=%.1f leaves/scan=%.1f\n", x[0], (double)x[1] / (double)(x[0] ? x[0] : 1), (double)x[2] / (double)(x[0] ? x[0] : 1));
+	}
+#endif
+#ifdef SP_PHASE_TIMERS
+	{
+		unsigned long long x[16] = {};
+		(void)hipMemcpy(x, c->counter.p, sizeof x, hipMemcpyDeviceToHost);
+		const double tot = (double)(x[8] + x[9] + x[10] + x[11] + x[12]);
+		fprintf(stderr, "[phase timers] wave-scans %llu; wave lifetime inside the scan by phase: stage 1 %.1f %%, list building + DMA issue %.1f %%, re-test rounds %.1f %%, exact turns %.1f %%, tile barrier %.1f %% (%.0f cycles per wave-scan)\n",
+		        x[13], 100.0 * x[8] / tot, 100.0 * x[9] / tot, 100.0 * x[10] / tot, 100.0 * x[11] / tot, 100.0 * x[12] / tot, tot / (double)(x[13] ? x[13] : 1));
 	}
 #endif
 #ifdef SP_FILTER_STATS

@@ -91,7 +91,7 @@ def test_many_samples_and_odd_counts(hip, O, scenes):
     hip.set_scene(t, m)
     for spp in (1, 2, 3, 255, 257):
         want = O.render_counter(rays, t, m, spp, 11)
-        for v in (6, 7):
+        for v in [v for v in VARIANTS if v >= 3]:          # incl. rpl_cylw4s: four consecutive samples of a pixel per lane
             img, acc = hip.render(rays, 23, 17, spp, seed=11, flags=v, want_accum=True)
             assert np.array_equal(img, want[0]) and np.array_equal(acc, want[1]), (spp, v)
             assert hip.stats()["scans_executed"] == want[2]
@@ -127,12 +127,13 @@ def test_fuzz_filter_scan_against_exact_scan(hip):
         src = rng.integers(-1, n, nr).astype(np.int32)
         d_rays, d_src = torch.from_numpy(rays).cuda(), torch.from_numpy(src).cuda()
         res = {}
-        for var in (2, 3, 5):
+        two_stage = [v for v in VARIANTS if v >= 3]
+        for var in [2] + two_stage:
             di = torch.zeros(nr, dtype=torch.int32, device="cuda"); dd = torch.zeros(nr, dtype=torch.float32, device="cuda")
             hip.closest_hit_device(d_rays.data_ptr(), nr, di.data_ptr(), dd.data_ptr(), d_src_idx=d_src.data_ptr(), flags=var)
             torch.cuda.synchronize()
             res[var] = (di.cpu().numpy(), dd.cpu().numpy().view(np.uint32))
-        for var in (3, 5):
+        for var in two_stage:
             assert np.array_equal(res[var][0], res[2][0]) and np.array_equal(res[var][1], res[2][1]), (it, var, n, size, spread)
         assert (res[2][0] >= 0).mean() > 0.02, (it, n, size, spread)     # the rays do hit things
 
