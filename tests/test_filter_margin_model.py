@@ -278,3 +278,95 @@ def test_matrix_pipe_filter_is_conservative_and_implies_the_slab_reject():
     slack = (np.abs(gmu) - np.abs(tu))[reject] / (U * mag[reject])
     assert slack.min() > 2 * 44.0, slack.min()
     print(f"matrix-pipe filter: rejects {reject.mean():.3f} (f32 cylinder filter: {rej32.mean():.3f}); smallest slab slack among its rejections {slack.min():.0f} u (needed 88 u)")
+
+
+def _matrix_pipe_x(pos, d, v0, v1, v2):
+    """The matrix-pipe side product g^ and the scaled H^, D^, Dq^ of every pair, exactly as in the test above (class = dominant
+    axis of the longest edge, powers-of-two scalings, t = half(P_a)/P_a, three half products per term)."""
+    n = pos.shape[0]
+    acc, a_f, sh, vq, e1, e2 = strict(pos, d, v0, v1, v2)
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    cd = e2d - e1d
+    l1, l2, lc = (e1d ** 2).sum(1), (e2d ** 2).sum(1), (cd ** 2).sum(1)
+    use_u, use_v = (l2 >= l1) & (l2 >= lc), ~((l2 >= l1) & (l2 >= lc)) & (l1 >= lc)
+    w = np.where(use_u[:, None], e2d, np.where(use_v[:, None], e1d, cd))
+    p0 = np.where(use_u[:, None] | use_v[:, None], v0, v1)
+    p1 = np.where(use_u[:, None], v1, np.where(use_v[:, None], v2, v0))
+    a, b, c, beta, gamma, mc, H = cyl_records(w, p0, p1)
+    idx = np.arange(n)
+    P = cross(pos, d)
+    rv = F(max(np.abs(v).sum(axis=1).max() for v in (v0, v1, v2)))
+    S = F(2.0 ** (np.floor(np.log2(float(rv))) + 2))
+    dmax = np.abs(d).max(axis=1)
+    s_d = (2.0 ** -np.floor(np.log2(dmax.astype(np.float64)))).astype(F)
+    kP, kN, kC = (s_d * F(16.0 / S)).astype(F), (F(16.0) * s_d).astype(F), (s_d * F(256.0 / S)).astype(F)
+    D = (np.sqrt(((d * d)[:, 0] + (d * d)[:, 1]) + (d * d)[:, 2]).astype(F) * F(1.0 + 2.0 ** -21)).astype(F)
+    d1 = np.abs(d).sum(axis=1).astype(np.float64)
+    p1n = np.abs(pos).sum(axis=1).astype(np.float64)
+    Dq = np.maximum((F(2.0 ** -16 * 1.01) * (d1 * (p1n + 2.0 * float(rv))).astype(F) * F(1.0 + 2.0 ** -20)).astype(F), F(1e-37))
+    Pa_, Pb_, Pc_ = (P[idx, a] * kP).astype(F), (P[idx, b] * kP).astype(F), (P[idx, c] * kP).astype(F)
+    ah = Pa_.astype(np.float16).astype(F)
+    big = np.abs(Pa_) >= F(2.0 ** -10)
+    with np.errstate(all="ignore"):
+        t = np.where(big, (ah.astype(np.float64) / Pa_.astype(np.float64)).astype(F), F(1.0)).astype(F)
+    extra = np.where(big, F(0.0), (np.abs(Pa_ - ah) * F(16.0)).astype(F)).astype(F)
+    ray_vals = [(Pb_ * t).astype(F), (Pc_ * t).astype(F)] + [((-d[:, k]) * kN * t).astype(F) for k in range(3)]
+    tri_vals = [(F(16.0) * beta).astype(F), (F(16.0) * gamma).astype(F)] + [(mc[:, k] * F(16.0 / S)).astype(F) for k in range(3)]
+    g = 16.0 * ah.astype(np.float64)
+    for rvl, tvl in zip(ray_vals, tri_vals):
+        rh, rl = _half_split(rvl)
+        th, tl = _half_split(tvl)
+        g = g + th * rh + tl * rh + th * rl
+    in_range = (p1n + 2.0 * float(rv)) <= 512.0 * float(S)
+    return dict(acc=acc, cls=a, g=g.astype(F), Hh=(H * F(256.0 / S)).astype(F), Dt=(D * s_d * t).astype(F),
+                Dqt=(((Dq * kC) * t + extra) * F(1.0 + 2.0 ** -20)).astype(F), in_range=in_range)
+
+
+def test_grouped_bound_of_the_matrix_pipe_filter_is_conservative():
+    """Round 3's stage 1 (sp_cylm_scan.h): ONE bound per group of four triangles of a class, x = fma(-Hmax, D^, min_i |g^_i|),
+    reject the group iff x > Dq^ -- 5 VALU instructions per 4 pairs instead of 8.  Groups of four triangles of one class tested
+    against one ray (aimed at one of the four):
+      1. a rejected group contains no pair the strict evaluation accepts;
+      2. a rejected group is rejected triangle by triangle too by the per-pair form the proof is written
+         for -- fl(m - Hmax D) <= fl(|g_i| - H_i D) because m <= |g_i|, Hmax >= H_i, D > 0 and rounding is monotone -- so the
+         grouped bound can only KEEP more;
+      3. with the group's H values close together (the prepass sorts every class by H) it keeps hardly more."""
+    rng = np.random.default_rng(80)
+    ng = 100_000
+    pos, d, v0, v1, v2 = make_pairs(rng, ng)
+    d = (d * np.where(rng.random((ng, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-3, 3, (ng, 1)))).astype(F)
+    # half of the rays are borrowed from another group: they pass the four triangles at a distance (what stage 1 is there to reject)
+    swap = rng.random(ng) < 0.5
+    pos = np.where(swap[:, None], np.roll(pos, 1, axis=0), pos).astype(F)
+    d = np.where(swap[:, None], np.roll(d, 1, axis=0), d).astype(F)
+    # three more triangles per ray: the first one moved and scaled a little (same longest edge direction: same class, similar H)
+    P4, D4, V0, V1, V2 = [pos], [d], [v0], [v1], [v2]
+    for k in range(3):
+        shift = (rng.normal(size=(ng, 3)) * np.abs(v1 - v0).max(axis=1, keepdims=True) * rng.choice([0.3, 3.0, 30.0], (ng, 1))).astype(F)
+        sc = rng.uniform(0.8, 1.25, (ng, 1)).astype(F)
+        P4.append(pos); D4.append(d)
+        V0.append((v0 + shift).astype(F)); V1.append((v0 + shift + (v1 - v0) * sc).astype(F)); V2.append((v0 + shift + (v2 - v0) * sc).astype(F))
+    cat = lambda xs: np.stack(xs, axis=1).reshape(ng * 4, 3)
+    q = _matrix_pipe_x(cat(P4), cat(D4), cat(V0), cat(V1), cat(V2))
+    r = lambda x: x.reshape(ng, 4)
+    same = (r(q["cls"]) == r(q["cls"])[:, :1]).all(axis=1)           # groups of one class (the stream is class-sorted)
+    assert same.mean() > 0.5
+    # the scaled ray values depend on the ray and the class only
+    assert (r(q["Dt"])[same] == r(q["Dt"])[same][:, :1]).all() and (r(q["Dqt"])[same] == r(q["Dqt"])[same][:, :1]).all()
+    m = np.abs(r(q["g"])).min(axis=1)
+    Hmax = r(q["Hh"]).max(axis=1)
+    Dt, Dqt = r(q["Dt"])[:, 0], r(q["Dqt"])[:, 0]
+    xg = fma(-Hmax, Dt, m)
+    rej_g = ~((xg - Dqt) < 0) & np.isfinite(xg) & r(q["in_range"])[:, 0] & same
+    xi = fma(-q["Hh"], q["Dt"], np.abs(q["g"]))
+    rej_i = r(~((xi - q["Dqt"]) < 0) & np.isfinite(xi) & q["in_range"])
+    acc = r(q["acc"])
+    assert acc[:, 0].mean() > 0.1 and acc[:, 1:].mean() > 0.001       # the aimed-at triangle and now and then a neighbour
+    assert not (rej_g[:, None] & acc).any(), int((rej_g[:, None] & acc).sum())
+    assert not (rej_g[:, None] & ~rej_i).any()                        # 2.
+    all_i = rej_i.all(axis=1) & same
+    assert 0.02 < rej_g.mean() < 0.9
+    lost = 1.0 - rej_g.sum() / max(all_i.sum(), 1)
+    assert lost < 0.08, lost                                           # 3. (H within a group spread over a factor 1.56 here; sorted streams are tighter)
+    print(f"grouped bound: rejects {rej_g.mean():.3f} of the groups, the four per-pair tests together {all_i.mean():.3f} ({lost:.2%} kept in addition)")
+

@@ -139,6 +139,7 @@ def test_vec3_rgba_every_quantisation_boundary(hip, O):
     assert np.array_equal(hip.selftest(5, big, big.shape[0]), O.device_math(5, big, big.shape[0]))
 
 
+@gpu
 def test_matrix_pipe_side_product_accuracy(hip):
     """sp_cylm_scan.h stage 1: the side product of one (triangle, ray) pair through v_mfma_f32_32x32x16_f16 -- operands split
     into two halves each, three half products per term, 16 products accumulated by the instruction -- against the same 16
@@ -167,3 +168,37 @@ def test_matrix_pipe_side_product_accuracy(hip):
     prod = 16.0 * q[:, 10].astype(np.float64) + (q[:, :5].astype(np.float64) * q[:, 5:10].astype(np.float64)).sum(1)
     floor = 2.0 ** -24 * (np.abs(q[:, :5]).sum(1) + np.abs(q[:, 5:10]).sum(1))
     assert (np.abs(ref - prod) <= 3.0 * 2.0 ** -22 * mag + floor).all()
+
+
+@gpu
+def test_matrix_pipe_keeps_subnormal_halves(hip):
+    """The error budget of sp_cylm_scan.h's stage 1 counts on two things the hardware is free to do otherwise: the float -> half
+    conversion must keep subnormal halves (values below 2^-14 become multiples of 2^-24 instead of zero: the `lo` parts of small
+    operands), and the f16 matrix instruction must multiply them as such.  One operand pair per item carries a product that exists
+    ONLY if both hold: a subnormal half (2^-24 ... 2^-15) times a large half; everything else in the item is zero."""
+    n = 4096
+    rng = np.random.default_rng(66)
+    q = np.zeros((n, 12), dtype=np.float32)
+    k = rng.integers(1, 1024, n)                                  # subnormal halves: k * 2^-24, k < 1024
+    big = np.float16(rng.uniform(256, 2048, n)).astype(np.float32)
+    slot = rng.integers(0, 5, n)
+    side = rng.random(n) < 0.5                                    # the subnormal on the triangle side or on the ray side
+    sub = (k * 2.0 ** -24).astype(np.float32)
+    q[np.arange(n), slot] = np.where(side, sub, big)
+    q[np.arange(n), 5 + slot] = np.where(side, big, sub)
+    got = hip.selftest(6, q, n).reshape(-1, 2).astype(np.float64)
+    want = sub.astype(np.float64) * big.astype(np.float64)        # exact in double, and in the instruction's f32 accumulator
+    assert (want > 0).all()
+    assert np.array_equal(got[:, 0], want), (np.abs(got[:, 0] - want).max(), int((got[:, 0] == 0).sum()))
+    # and a `lo` part that is itself subnormal: v = hi + lo with lo = k * 2^-24 must come through the split intact
+    hi = np.float16(rng.uniform(0.01, 0.03, n)).astype(np.float32)            # ulp(hi) = 2^-17 .. 2^-16: lo < 2^-17 is subnormal
+    lo = (rng.integers(4, 64, n) * 2.0 ** -24).astype(np.float32)
+    q[:] = 0
+    q[np.arange(n), slot] = hi + lo                                            # exact in float
+    q[np.arange(n), 5 + slot] = big
+    got = hip.selftest(6, q, n).reshape(-1, 2).astype(np.float64)
+    want = (hi.astype(np.float64) + lo.astype(np.float64)) * big.astype(np.float64)
+    # (the two products are added in the f32 accumulator: one rounding; a flushed `lo` would be off by 2^-18 or more)
+    assert (np.abs(got[:, 0] - want) <= 2.0 ** -22 * want).all(), (np.abs(got[:, 0] - want) / want).max()
+    assert (np.abs(hi.astype(np.float64) * big - want) > 2.0 ** -20 * want).all()              # the check has teeth: dropping lo would show
+
