@@ -115,13 +115,21 @@ class ClockSampler:
         return (sum(self.samples) / len(self.samples)) if self.samples else None
 
 
-def profile_entry(fname, key):
-    """Figures that only a profiler pass can supply (PMC counters, the statistics build), committed under profiles/."""
+def profile_entry(fname, key, lib_hash=None):
+    """Figures that only a profiler pass can supply (PMC counters, the statistics build), committed under profiles/.
+    Every entry is stamped with the source/flags hash of the library it was measured on (sphip_build_info); an entry whose stamp
+    differs from the loaded library's is NOT used: returns (None, reason)."""
     path = os.path.join(ROOT, "profiles", fname)
     try:
-        return json.load(open(path)).get(key)
-    except Exception:
-        return None
+        e = json.load(open(path)).get(key)
+    except Exception as ex:
+        return None, f"profiles/{fname} unreadable ({ex})"
+    if e is None:
+        return None, f"no entry {key!r} in profiles/{fname}: no profiler pass committed for this configuration and kernel"
+    if lib_hash is not None and e.get("source_hash") != lib_hash:
+        return None, (f"profiles/{fname}[{key!r}] was measured on sources {e.get('source_hash', 'unstamped')}, the loaded library is built from "
+                      f"{lib_hash}: stale, not used (re-run tools/collect_profiles.sh + tools/publish_profiles.sh)")
+    return e, None
 
 
 def host_cores() -> int:
@@ -154,6 +162,7 @@ def cpu_baseline(tris, mats, args):
     w, h, spp = args.cpu_w, args.cpu_h, args.cpu_spp
     nominal = w * h * spp * 5
     info = None
+    quantum = 0.0
     if O.have_ref():
         try:
             _, info = O.ref_run("render", w, h, spp, tris, mats, threads=cores, return_info=True)
@@ -163,6 +172,9 @@ def cpu_baseline(tris, mats, args):
     if info and "seconds" in info:
         secs, kind = info["seconds"], "reference"
         what = "unmodified reference cpu_renderer (oracle/_ref/spath_ref)"
+        # render_pt_mt returns when its 250 ms completion poll next fires (reference src/cpu_renderer.cpp:172-178): the measured
+        # time is the compute time rounded UP to the poll grid -- what a caller of the reference waits, and up to 0.25 s more than the work
+        quantum = 0.25
     else:
         rays = view.Camera(w, h).get_viewport()
         O.lib()
@@ -171,7 +183,8 @@ def cpu_baseline(tris, mats, args):
         secs, kind = time.perf_counter() - t0, "port"
         what = "C restatement of cpu_renderer (oracle/liboracle.so)"
     return {"value": nominal / secs / 1e6, "unit": "Mray/s", "cores": cores, "kind": kind,
-            "seconds": round(secs, 3),
+            "seconds": round(secs, 3), "seconds_poll_quantum": quantum,
+            "value_range": [round(nominal / secs / 1e6, 5), round(nominal / max(secs - quantum, 1e-9) / 1e6, 5)],
             "sample": f"{what}, same scene ({tris.shape[0]} triangles), {w}x{h} x {spp} spp x 5 bounces, {cores} threads"}
 
 
@@ -194,7 +207,7 @@ def main():
     ap.add_argument("--no-worst-case", action="store_true", help="skip the (untimed) large-triangle scene figure")
     ap.add_argument("--cpu-w", type=int, default=192)
     ap.add_argument("--cpu-h", type=int, default=108)
-    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-spp", type=int, default=32, help="the CPU sample's spp (default: ~30 s of the reference on 16 threads, 0.25 s poll quantum < 1 %)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -249,6 +262,7 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     image = None
+    gather_s = []                      # host time of the exchange of every timed step (N > 1), this rank
 
     def step(i_timed=None):
         nonlocal image
@@ -258,7 +272,13 @@ def main():
         if i_timed is not None:
             ev[i_timed][1].record()
         if world > 1:
+            if i_timed is not None:
+                torch.cuda.synchronize()           # (the gather needs the finished tiles anyway; this separates kernel from exchange time)
+                tg = time.perf_counter()
             image = gather(local.cpu() if rehearsal else local)
+            if i_timed is not None:
+                torch.cuda.synchronize()
+                gather_s.append(time.perf_counter() - tg)
         else:
             image = local
 
@@ -351,14 +371,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([float(st["scans_executed"]), max(kernel_ms) if kernel_ms else 0.0], dtype=torch.float64, device=cdev)
+        s = torch.tensor([float(st["scans_executed"]), max(kernel_ms) if kernel_ms else 0.0, 1e3 * sum(gather_s) / max(len(gather_s), 1)],
+                         dtype=torch.float64, device=cdev)
         s_sum = s.clone(); dist.all_reduce(s_sum, op=dist.ReduceOp.SUM)
         s_max = s.clone(); dist.all_reduce(s_max, op=dist.ReduceOp.MAX)
         s_min = s.clone(); dist.all_reduce(s_min, op=dist.ReduceOp.MIN)
         scans_per_step, kern_ms_max, kern_ms_min = float(s_sum[0].item()), float(s_max[1].item()), float(s_min[1].item())
+        gather_ms_max, gather_ms_min = float(s_max[2].item()), float(s_min[2].item())
     else:
         scans_per_step = float(st["scans_executed"])
         kern_ms_max = kern_ms_min = (sum(kernel_ms) / len(kernel_ms) if kernel_ms else 0.0)
+        gather_ms_max = gather_ms_min = 0.0
 
     if rank == 0:
         nominal = W * H * SPP * 5
@@ -370,16 +393,23 @@ def main():
         achieved = my_scans * NT * BYTES_PER_TEST / avg_kernel_s / 1e9
         kname = capi.load().sphip_kernel_name(st["kernel_variant"]).decode()
         key = f"{NT}tris_{W}x{H}x{SPP}_g{world}_{kname}"
-        tr = profile_entry("hbm_traffic.json", key) or {}
-        traffic = tr.get("hbm_bytes_per_launch")
-        vi = profile_entry("valu_issue.json", key) or {}
-        if not vi and world > 1:
+        lib_hash = capi.build_source_hash()
+        tr, tr_why = profile_entry("hbm_traffic.json", key, lib_hash)
+        if tr is None and world > 1:
+            tr, tr_why = profile_entry("hbm_traffic.json", f"{NT}tris_{W}x{H}x{SPP}_g1_{kname}", lib_hash)
+            tr = None                              # (a 1-GPU launch's bytes are not a shard's bytes: reported as unavailable)
+        traffic = (tr or {}).get("hbm_bytes_per_launch")
+        vi, vi_why = profile_entry("valu_issue.json", key, lib_hash)
+        if vi is None and world > 1:
             # instructions per ray-triangle test are a property of the kernel and the scene, not of the GPU count: rank 0's shard of
             # an N-GPU run executes the same kernel on the same scene as the committed 1-GPU PMC pass
-            vi = dict(profile_entry("valu_issue.json", f"{NT}tris_{W}x{H}x{SPP}_g1_{kname}") or {})
+            vi, vi_why = profile_entry("valu_issue.json", f"{NT}tris_{W}x{H}x{SPP}_g1_{kname}", lib_hash)
             if vi:
+                vi = dict(vi)
                 vi["source"] = vi.get("source", "") + " [1-GPU pass of the same kernel and scene, applied to rank 0's shard]"
-        fs = profile_entry("filter_stats.json", f"{NT}tris_{W}x{H}_{kname}") or {}
+        vi = vi or {}
+        fs, _ = profile_entry("filter_stats.json", f"{NT}tris_{W}x{H}_{kname}", lib_hash)
+        fs = fs or {}
         tests_per_s = my_scans * NT / avg_kernel_s
         lane_instr = vi.get("lane_instr_per_test")
         valu_achieved = tests_per_s * lane_instr / 1e12 if lane_instr else None
@@ -394,7 +424,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (stage-1 filter: f16 hi/lo products on the matrix pipe, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": f"closed-room {NT} triangles, {W}x{H}, {SPP} spp, 5 bounces (BASELINE.json configs[2])"
@@ -411,6 +441,10 @@ def main():
             "reference_runs_untimed": exact_only,
             "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
             "kernel_ms_per_rank": {"min": round(kern_ms_min, 3), "max": round(kern_ms_max, 3)},
+            "gather_ms_per_step": ({"min": round(gather_ms_min, 3), "max": round(gather_ms_max, 3),
+                                    "note": "host time of the RCCL gather of the finished tiles + un-permute on rank 0, per timed step, slowest / fastest rank"}
+                                   if world > 1 else None),
+            "library_source_hash": lib_hash,
             "worst_case_untimed": worst,
             "roofline": {
                 # the binding roof: FP32 vector instruction issue (HBM is idle, see `traffic`; the f16 matrix pipe carries stage 1's side
@@ -425,7 +459,8 @@ def main():
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
                 "tests_per_s": round(tests_per_s, 1),
                 "lane_instr_per_test": lane_instr,
-                "lane_instr_source": vi.get("source", "no PMC pass committed for this configuration and kernel: valu fraction unavailable"),
+                "lane_instr_source": vi.get("source", vi_why),
+                "traffic_source": (tr or {}).get("method", tr_why) if traffic is None else tr.get("method"),
                 "peak_definition": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md); one wave64 VALU instruction = 2 issue cycles",
                 # what a pure stream of independent v_fmac_f32 issues on this chip at the kernel's 4 waves per SIMD (tools/valu_bench.hip,
                 # profiles/r01_valu_microbench_extended.log: 56.7 T lane-instr/s; v_fma_f32 50-55, three-source min/med ops 31.5)

@@ -121,6 +121,9 @@ const char* sphip_last_error(const sphip_t* ctx);   /* ctx may be NULL: error of
 const char* sphip_description(const sphip_t* ctx);  /* renderer::get_description  src/renderer.h:26 */
 int  sphip_abi_version(void);
 const char* sphip_kernel_name(int variant);         /* NULL when the variant does not exist */
+const char* sphip_build_info(void);                 /* "src=<16 hex digits>": hash of the sources and compiler flags this library was built
+                                                       from (__graft_entry__.source_hash), "src=unknown" for a hand-made build; profiler-derived
+                                                       figures under profiles/ carry the same stamp */
 int  sphip_kernel_available(int variant);           /* 1 when this build of the library carries the variant (the shipped build: the
                                                        default scan, the exact-only scans, one f32 filter scan for A/B runs and the
                                                        opt-in BVH; -DSP_ALL_VARIANTS builds: every generation), else 0 */

@@ -30,7 +30,7 @@ SYMBOLS = (
     "sphip_kernel_name", "sphip_set_scene", "sphip_render", "sphip_set_scene_device",
     "sphip_render_device", "sphip_closest_hit_device", "sphip_get_stats", "sphip_viewport_device", "sphip_render_camera",
     "sphip_create_multi", "sphip_device_count", "sphip_plan_tile_rows", "sphip_plan_shard", "sphip_selftest_device",
-    "sphip_kernel_available", "sphip_selftest_stage1",
+    "sphip_kernel_available", "sphip_selftest_stage1", "sphip_build_info",
 )
 GATHER_NONE, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 
@@ -111,6 +111,9 @@ def load():
     if hasattr(L, "sphip_kernel_available"):
         L.sphip_kernel_available.restype = C.c_int
         L.sphip_kernel_available.argtypes = [C.c_int]
+    if hasattr(L, "sphip_build_info"):
+        L.sphip_build_info.restype = C.c_char_p
+        L.sphip_build_info.argtypes = []
     if hasattr(L, "sphip_selftest_stage1"):
         L.sphip_selftest_stage1.restype = C.c_int
         L.sphip_selftest_stage1.argtypes = [vp, vp, sz, vp, vp, vp, C.POINTER(C.c_uint32)]
@@ -137,6 +140,14 @@ def kernel_variants():
         out[n.decode()] = i
         i += 1
     return out
+
+
+def build_source_hash() -> str:
+    """The source/flags hash compiled into the loaded library ("unknown" for hand-made builds and libraries of earlier rounds)."""
+    L = load()
+    if not hasattr(L, "sphip_build_info"):
+        return "unknown"
+    return L.sphip_build_info().decode().split("src=")[-1]
 
 
 def available_variants():

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <thread>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -524,7 +525,13 @@ struct Rccl {
 } g_rccl;
 constexpr int kNcclUint8 = 1;      // ncclDataType_t::ncclUint8 (rccl.h)
 
+// (once per process, under a lock: contexts may be created from several threads; the table is never changed afterwards and the
+// library stays loaded)
 void* load_rccl() {
+	static std::mutex mu;
+	static void* loaded = nullptr;
+	std::lock_guard<std::mutex> lock(mu);
+	if (loaded) return loaded;
 	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
 	for (const char* n : names) {
 		void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -536,7 +543,8 @@ void* load_rccl() {
 		g_rccl.send = (nccl_send_t)dlsym(h, "ncclSend");
 		g_rccl.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
 		g_rccl.errstr = (nccl_errstr_t)dlsym(h, "ncclGetErrorString");
-		if (g_rccl.init_all && g_rccl.destroy && g_rccl.group_start && g_rccl.group_end && g_rccl.send && g_rccl.recv) return h;
+		if (g_rccl.init_all && g_rccl.destroy && g_rccl.group_start && g_rccl.group_end && g_rccl.send && g_rccl.recv) { loaded = h; return h; }
+		g_rccl = Rccl{};
 		dlclose(h);
 	}
 	return nullptr;
@@ -555,9 +563,25 @@ int multi_set_scene(sphip_ctx* c, const float* tris, const float* mats, size_t n
 	return SPHIP_OK;
 }
 
-// rays != nullptr: the caller's viewport (host array, w*h rays); else cam: every device generates the rays of its own tiles
+int multi_render_impl(sphip_ctx* c, const float* rays, const sphip_camera* cam, size_t w, size_t h, size_t n_samples, uint64_t seed, int mode, int flags,
+                      uint8_t* out_rgba, float* out_accum);
+
+// rays != nullptr: the caller's viewport (host array, w*h rays); else cam: every device generates the rays of its own tiles.
+// Whatever goes wrong on one device, no device is left with work in flight when the call returns: the next call may free or
+// regrow the buffers that work reads and writes.
 int multi_render(sphip_ctx* c, const float* rays, const sphip_camera* cam, size_t w, size_t h, size_t n_samples, uint64_t seed, int mode, int flags,
                  uint8_t* out_rgba, float* out_accum) {
+	const int rc = multi_render_impl(c, rays, cam, w, h, n_samples, seed, mode, flags, out_rgba, out_accum);
+	if (rc != SPHIP_OK) {
+		for (sphip_ctx* k : c->kids)
+			if (hipSetDevice(k->device) == hipSuccess && k->own_stream) (void)hipStreamSynchronize(k->own_stream);
+		(void)hipGetLastError();
+	}
+	return rc;
+}
+
+int multi_render_impl(sphip_ctx* c, const float* rays, const sphip_camera* cam, size_t w, size_t h, size_t n_samples, uint64_t seed, int mode, int flags,
+                      uint8_t* out_rgba, float* out_accum) {
 	if (!c->have_scene) return fail(c, SPHIP_E_STATE, "render called before a scene was set");
 	if (!out_rgba || w == 0 || h == 0 || w * h > 0xffffffffull) return fail(c, SPHIP_E_INVALID, "bad render arguments (w=%zu h=%zu)", w, h);
 	if (mode == SPHIP_MODE_PT && (n_samples == 0 || n_samples > 0x7fffffffull))
@@ -718,6 +742,11 @@ const char* sphip_kernel_name(int variant) {
 	if (variant < 0 || variant > kVariantLast) return nullptr;
 	return kVariantNames[variant];
 }
+
+#ifndef SP_SOURCE_HASH
+#define SP_SOURCE_HASH "unknown"
+#endif
+const char* sphip_build_info(void) { return "src=" SP_SOURCE_HASH; }
 
 int sphip_kernel_available(int variant) { return variant_built(variant) ? 1 : 0; }
 

@@ -10,6 +10,7 @@
 #include "spath_hip.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -111,7 +112,15 @@ struct hip_r : public basic_renderer {
 } // namespace
 
 namespace hip_renderer {
+	// One GPU: device 0, or the devices listed in SPATH_HIP_DEVICES.  Several GPUs behind one renderer are opt-in (get_on /
+	// get_all_devices): the cross-device exchange has not run on a multi-GPU node yet.
 	scene::renderer* get(const int w, const int h) {
+		if (std::getenv("SPATH_HIP_DEVICES")) return new hip_r(w, h, 0, 0);
+		const int first = 0;
+		return new hip_r(w, h, &first, 1);
+	}
+
+	scene::renderer* get_all_devices(const int w, const int h) {
 		return new hip_r(w, h, 0, 0);
 	}
 

@@ -8,11 +8,12 @@ namespace hip_renderer {
 	// Returns a new renderer owned by the caller (the reference wraps it in std::unique_ptr,
 	// src/main.cpp:242-244).  Throws std::runtime_error when no usable HIP device exists, like the
 	// reference's GPU peers do from their constructors (src/cl_renderer.cpp:155-187).
-	// Drives EVERY visible GPU of the node (or those listed in the environment variable SPATH_HIP_DEVICES, e.g. "0" for one):
-	// pixel-row tiles dealt round-robin, one gather to the first device, same image bit for bit as on one GPU.
+	// One GPU: device 0 (or the devices listed in the environment variable SPATH_HIP_DEVICES, e.g. "0,1,2,3").
 	extern scene::renderer* get(const int w, const int h);
-	// the same on an explicit device list (a device may be listed more than once)
+	// Opt-in: several GPUs of the node behind one renderer -- pixel-row tiles dealt round-robin, one gather to the first device,
+	// same image bit for bit as on one GPU.  An explicit device list (a device may be listed more than once), or every visible GPU.
 	extern scene::renderer* get_on(const int w, const int h, const int* device_ids, const int n_devices);
+	extern scene::renderer* get_all_devices(const int w, const int h);
 	extern int device_count(scene::renderer* r);
 
 	// Optional knobs of this backend (not part of the reference interface): the RNG seed of the next

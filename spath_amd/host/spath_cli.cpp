@@ -5,7 +5,7 @@
 //
 //   spath_cli [--scene default|FILE.bin] [--w 640 --h 480] [--spp 128] [--mode pt|flat]
 //             [--mov x y z] [--rot x y z] [--focal f] [--seed n] [--flags n] [--primary-reuse] [--out image.ppm|image.rgba] [--frames n]
-//             [--device-viewport] [--gpus n | --devices 0,1,...]
+//             [--device-viewport] [--gpus n | --devices 0,1,... | --all-gpus]
 // --out: .ppm (binary P6), .png (8-bit RGB, stored deflate blocks: no compression library needed), anything else = raw RGBA8
 #include "hip_renderer.h"
 #include "spath_hip.h"
@@ -124,7 +124,8 @@ int main(int argc, char** argv) {
 	try {
 		std::string scene_arg = "default", mode = "pt", out_path;
 		bool device_viewport = false;
-		std::vector<int> devices;                                    // empty: every visible GPU (hip_renderer::get)
+		std::vector<int> devices;                                    // empty: one GPU (hip_renderer::get: device 0 or SPATH_HIP_DEVICES)
+		bool all_gpus = false;
 		int w = 640, h = 480, frames = 1, flags = 0;                 // window default of the reference (main.cpp:238-239)
 		size_t spp = 128;                                            // main.cpp:44
 		unsigned long long seed = 1;
@@ -143,6 +144,7 @@ int main(int argc, char** argv) {
 			else if (k == "--frames") { need(1); frames = std::atoi(argv[++i]); }
 			else if (k == "--out") { need(1); out_path = argv[++i]; }
 			else if (k == "--device-viewport") device_viewport = true;
+			else if (k == "--all-gpus") all_gpus = true;
 			else if (k == "--gpus") { need(1); const int n = std::atoi(argv[++i]); devices.clear(); for (int d = 0; d < n; ++d) devices.push_back(d); }
 			else if (k == "--devices") { need(1); devices.clear(); for (const char* p = argv[++i]; *p;) { char* e = 0; devices.push_back((int)std::strtol(p, &e, 10)); if (e == p) throw std::runtime_error("bad --devices list"); p = *e ? e + 1 : e; } }
 			else if (k == "--mov" || k == "--rot") { need(3); moves.push_back(std::make_pair(k[2], geom::vec3(std::atof(argv[i + 1]), std::atof(argv[i + 2]), std::atof(argv[i + 3])))); i += 3; }
@@ -154,8 +156,8 @@ int main(int argc, char** argv) {
 		if (scene_arg == "default") default_scene(tris, mats);
 		else if (!load_scene(scene_arg.c_str(), tris, mats)) throw std::runtime_error("cannot read scene file " + scene_arg);
 
-		std::unique_ptr<scene::renderer> r(devices.empty() ? hip_renderer::get(w, h)      // main.cpp:242-244
-		                                                   : hip_renderer::get_on(w, h, devices.data(), (int)devices.size()));
+		std::unique_ptr<scene::renderer> r(!devices.empty() ? hip_renderer::get_on(w, h, devices.data(), (int)devices.size())      // main.cpp:242-244
+		                                   : all_gpus ? hip_renderer::get_all_devices(w, h) : hip_renderer::get(w, h));
 		hip_renderer::set_seed(r.get(), seed);
 		hip_renderer::set_flags(r.get(), flags);
 		std::printf("Current renderer: %s [%d device(s)]\n", r->get_description(), hip_renderer::device_count(r.get()));     // main.cpp:30-32

@@ -176,7 +176,7 @@ def _unpinned_lib():
         sys.path.insert(0, ROOT)
         import __graft_entry__ as g
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + g.HIPCC_FLAGS + ["-DSP_CYLM_UNPINNED", "-o", out, g.HIP_SRC], cwd=ROOT)
+        subprocess.check_call(g.hipcc_command(out, ["-DSP_CYLM_UNPINNED"]), cwd=ROOT)
     return out
 
 

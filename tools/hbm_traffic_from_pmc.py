@@ -1,8 +1,11 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a one-step bench.py run into profiles/hbm_traffic.json.
-usage: python tools/hbm_traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <key>
+usage: python tools/hbm_traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <key> [round [source hash of the measured library]]
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 as MI355X_MICROARCH.md prescribes."""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as _ge
+SOURCE_HASH = _ge.source_hash()      # the sources/flags the measured library was built from (run this right after the measurement)
 
 
 def total(path, counter):
@@ -26,7 +29,7 @@ entry = {
               "here are 8-B and 4-B per lane, for which the guide calls the factor uncalibrated, so this is an upper bound). The traffic is the "
               "path-history work buffer (8 B per scan written and read back) and the per-sample radiance scratch of the sample-chunked launch, "
               "not triangle data: the 320 KB + 480 KB record streams stay in L2/LDS",
-    "round": 2,
+    "round": int(sys.argv[4]) if len(sys.argv) > 4 else 3, "source_hash": sys.argv[5] if len(sys.argv) > 5 else SOURCE_HASH,
 }
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}

@@ -5,9 +5,13 @@ usage: python tools/valu_issue_from_pmc.py <counter_collection.csv> <bench line 
 Writes profiles/valu_issue.json[key], key = '<tris>tris_<W>x<H>x<spp>_g<gpus>_<kernel>', which bench.py reads."""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as _ge
+SOURCE_HASH = _ge.source_hash()      # the sources/flags the measured library was built from (run this right after the measurement)
 rows = list(csv.DictReader(open(sys.argv[1])))
 bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
-rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+SOURCE_HASH = bench.get("library_source_hash") or SOURCE_HASH     # the library the PMC pass itself ran on, when the bench line says
 per, launches = {}, {}
 for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -25,7 +29,7 @@ entry = {
     "counters": {k: v for k, v in sorted(per[dom].items())},
     "source": f"rocprofv3 --pmc pass of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` (profiles/{os.path.basename(sys.argv[1])}): "
               f"SQ_INSTS_VALU x 64 / (scans x n_tris); reproduce with tools/pmc_summary.py",
-    "round": rnd,
+    "round": rnd, "source_hash": SOURCE_HASH,
 }
 for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD"):
     if k in per[dom]:
