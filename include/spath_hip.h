@@ -197,14 +197,16 @@ int sphip_selftest_device(sphip_t* ctx, int what, const void* in, size_t n, void
  * geom::ray_intersect (src/geom.h:197-222) -- for n_rays host rays (a multiple of 64) against the context's scene, formed
  * exactly as the render kernels form it (same ray setup, same fragment code, same tiles).  A test can then assert, pair by
  * pair, that no pair the reference accepts has its bit clear, instead of observing the filter only through the closest hit.
- *   *tiles_out         256-triangle tiles of the scene's stream (call with out_words = NULL first to size the outputs)
- *   out_words[(k * tiles + t) * 2 + rb]   word of "lane" k (k = 64 b + l) for tile t: bit 31 - (4 f + j) set = the group of four
- *                      triangles 8 f + 2 j + (l >> 5) of tile t SURVIVES for ray 64 b + (l & 31) + 32 rb (f < 8, j < 4)
- *   out_tri[((k * tiles + t) * 2 + rb) * 4 + f / 2]   (may be NULL) the same side products tested per TRIANGLE with the triangle's own
+ *   *tiles_out         bits 0-19: tiles of the scene's stream, bits 20-31: T = triangles per tile (call with out_words = NULL first
+ *                      to size the outputs); W = T / 256 words per ray block below
+ *   out_words[((k * tiles + t) * 2 + rb) * W + w]   word w of "lane" k (k = 64 b + l) for tile t: bit 31 - (4 f + j) set = the group of four
+ *                      triangles 8 (8 w + f) + 2 j + (l >> 5) of tile t SURVIVES for ray 64 b + (l & 31) + 32 rb (f < 8, j < 4)
+ *   out_tri[((k * tiles + t) * 2 + rb) * (T / 64) + f / 2]   (may be NULL) the same side products tested per TRIANGLE with the triangle's own
  *                      cylinder radius (the per-pair form of the test): bit 31 - (16 (f & 1) + 4 j + i) set = triangle
- *                      32 f + 8 j + 4 (l >> 5) + i of tile t survives for that ray.  Stronger than the group bit: a set triangle
- *                      bit implies the set group bit
- *   out_order[t * 256 + 4 g + u]          index of the triangle at place u of group g of tile t (n_tris = padding)
+ *                      32 f + 8 j + 4 (l >> 5) + i of tile t survives for that ray (f < T / 32).  Stronger than the group bit: a set
+ *                      triangle bit implies the set group bit
+ *   out_order[t * T + 4 g + u]            index of the triangle at place u of group g of tile t (n_tris = padding; a triangle that
+ *                      appears nowhere is in the "big" class: no filter, tested by every ray)
  * Blocking; host pointers; single-device contexts. */
 int sphip_selftest_stage1(sphip_t* ctx, const float* rays, size_t n_rays, uint32_t* out_words, uint32_t* out_tri, int32_t* out_order, uint32_t* tiles_out);
 

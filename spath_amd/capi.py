@@ -304,36 +304,38 @@ class Context:
             rays = np.concatenate([rays, np.repeat(rays[-1:], n_pad - n, axis=0)])
         tiles = C.c_uint32(0)
         self._check(self._L.sphip_selftest_stage1(self._h, None, 0, None, None, None, C.byref(tiles)), "sphip_selftest_stage1")
-        t = tiles.value
-        words = np.zeros(n_pad * t * 2, dtype=np.uint32)
-        tri = np.zeros(n_pad * t * 8, dtype=np.uint32) if per_triangle else None
-        order = np.zeros(t * 256, dtype=np.int32)
+        t, T = tiles.value & 0xFFFFF, tiles.value >> 20
+        W, G = T // 256, T // 4                                          # words per ray block, groups per tile
+        words = np.zeros(n_pad * t * 2 * W, dtype=np.uint32)
+        tri = np.zeros(n_pad * t * 2 * (T // 64), dtype=np.uint32) if per_triangle else None
+        order = np.zeros(t * T, dtype=np.int32)
         self._check(self._L.sphip_selftest_stage1(self._h, rays.ctypes.data, n_pad, words.ctypes.data, tri.ctypes.data if per_triangle else None,
                                                   order.ctypes.data, C.byref(tiles)), "sphip_selftest_stage1")
         nb = n_pad // 64
-        # words[(64 b + l), tile, rb]: bit 31 - (4 f + j) <-> group 8 f + 2 j + (l >> 5), ray 64 b + (l & 31) + 32 rb
-        w = words.reshape(nb, 2, 32, t, 2)                               # [block, half, column, tile, rb]
+        # words[(64 b + l), tile, rb, w]: bit 31 - (4 f + j) <-> group 8 (8 w + f) + 2 j + (l >> 5), ray 64 b + (l & 31) + 32 rb
+        w = words.reshape(nb, 2, 32, t, 2, W)                            # [block, half, column, tile, rb, word]
         bits = ((w[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)     # [..., k = 4 f + j]
-        k = np.arange(32)
-        surv = np.zeros((nb, 64, t, 64), dtype=bool)                     # [block, ray in block, tile, group]
+        wi, k = np.meshgrid(np.arange(W), np.arange(32), indexing="ij")
+        surv = np.zeros((nb, 64, t, G), dtype=bool)                      # [block, ray in block, tile, group]
         for hh in range(2):
-            grp = 8 * (k // 4) + 2 * (k % 4) + hh
+            grp = (64 * wi + 2 * k + hh).reshape(-1)                     # 8 (8 w + k // 4) + 2 (k % 4) + hh
             for rb in range(2):
-                surv[:, 32 * rb:32 * rb + 32, :, grp] = bits[:, hh, :, :, rb, :]
-        surv = np.repeat(surv.reshape(n_pad, t * 64), 4, axis=1)         # per stream position
+                surv[:, 32 * rb:32 * rb + 32, :, grp] = bits[:, hh, :, :, rb].reshape(nb, 32, t, W * 32)
+        surv = np.repeat(surv.reshape(n_pad, t * G), 4, axis=1)          # per stream position
         tsurv = None
         if per_triangle:
             # tri[(64 b + l), tile, rb, q]: bit 31 - (16 (f & 1) + 4 j + i), f = 2 q + (bit >= 16) <-> triangle 32 f + 8 j + 4 (l >> 5) + i
-            tw = tri.reshape(nb, 2, 32, t, 2, 4)
+            Q = T // 64
+            tw = tri.reshape(nb, 2, 32, t, 2, Q)
             tb = ((tw[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)   # [block, half, column, tile, rb, q, bit]
-            tsurv = np.zeros((nb, 64, t, 256), dtype=bool)
-            q, bit = np.meshgrid(np.arange(4), np.arange(32), indexing="ij")
+            tsurv = np.zeros((nb, 64, t, T), dtype=bool)
+            q, bit = np.meshgrid(np.arange(Q), np.arange(32), indexing="ij")
             f, j, i = 2 * q + bit // 16, (bit % 16) // 4, bit % 4
             for hh in range(2):
                 pos = (32 * f + 8 * j + 4 * hh + i).reshape(-1)
                 for rb in range(2):
-                    tsurv[:, 32 * rb:32 * rb + 32, :, pos] = tb[:, hh, :, :, rb].reshape(nb, 32, t, 128)
-            tsurv = tsurv.reshape(n_pad, t * 256)[:n]
+                    tsurv[:, 32 * rb:32 * rb + 32, :, pos] = tb[:, hh, :, :, rb].reshape(nb, 32, t, Q * 32)
+            tsurv = tsurv.reshape(n_pad, t * T)[:n]
         return surv[:n], tsurv, order
 
     def stats(self) -> dict:

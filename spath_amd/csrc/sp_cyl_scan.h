@@ -63,6 +63,7 @@ SP_DEV constexpr uint32_t cyl_slot(uint32_t group, uint32_t chunk) { return chun
 struct CylStream {
 	const float4* rec;       // class-major stream; every class starts on a tile boundary
 	const uint32_t* hdr;     // [0..2] triangles per class, [3..5] first tile of each class (k_cyl_offsets)
+	const float4* big;       // sp_cylm_scan.h only: exact records of the big class (3 float4 each), hdr[8] of them
 };
 
 // triangle u of group grp of a tile: q0 -> chunk u; (q1.x, q1.y) = (Mz, H) -> chunk 4 + u/2, half u%2; q1.z = index bits -> chunk 6, lane u

@@ -38,29 +38,39 @@
 // scaled Hmax of the groups, [fragment][lane half] x (the four groups j = 0..3 that half owns): one 16-B read per lane and
 // fragment -- followed by the A fragments [8 blocks of 32][64 lanes] x 16 B; 8 fragments x 4 group bits = one 32-bit word per
 // ray block (128 / 192-triangle tiles: -15 % / -4 %).  Build hooks for experiments: SP_EXP_NO_STAGE2 (timing only), SP_DBG_ALLBITS, SP_DBG_PRINT, SP_CYLM_UNPINNED.
-#pragma once
+//
+// THIS FILE IS INCLUDED TWICE (sp_cylm_both.h): once per workgroup shape, each copy in a namespace of its own --
+//   sp::cylm256   256 threads, 256-triangle tiles (four workgroups per CU)     scenes below kMBigSceneTris triangles
+//   sp::cylm512   512 threads, 512-triangle tiles (two workgroups per CU)      larger scenes
+// Larger tiles halve what a tile costs beyond its pairs (LDS-DMA issue, barrier, list pass, the half-filled last round of stage 2):
+// +7 % at 10^5 and +8 % at 10^6 triangles; eight waves per barrier wait longer for their slowest member, which costs more than that
+// where stage 2 is heavy: -2 % at 10^4 triangles, -20 % on the large-triangle scene (profiles/r03_cyl_scan_experiments.log).
+#ifndef SP_CYLM_NS
+#error "include sp_cylm_both.h, not this file"
+#endif
 
-#include "sp_cyl_scan.h"
-#include "sp_radix_sort.h"
-
-#include <type_traits>
-
-namespace sp {
+namespace sp { namespace SP_CYLM_NS {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
+// (time = a + b / tile with b / 256 = 19 % of the configs[2] frame for 256-thread workgroups: tiles of 128 / 192 / 256 triangles
+// 159.2 / 142.5 / 134.1 ms; a workgroup of 256 cannot afford more than 2 x 16 KB of tile buffers next to its lists)
 #ifndef SP_CYLM_TILE
-#define SP_CYLM_TILE 256
+#define SP_CYLM_TILE SP_CYLM_THREADS
 #endif
 
+constexpr uint32_t kMThreads = SP_CYLM_THREADS;   // threads per workgroup of the kernels over this scan
+constexpr uint32_t kMWaves = kMThreads / 64u;
 constexpr uint32_t kMTile = SP_CYLM_TILE;        // triangles per tile
-constexpr uint32_t kMGroups = kMTile / 4u;        // 64 groups of four
-constexpr uint32_t kMBlocks = kMTile / 32u;       // 8 fragments
-constexpr uint32_t kMRecQ = kMGroups * 8u;        // 512 float4: the f32 part
-constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 1024 float4 = 16 KB
-static_assert(kMTileQ % 256u == 0u, "whole workgroup LDS-DMA passes");
-static_assert(kMGroups <= 64u && kMBlocks * 4u <= 32u, "6-bit group index in a list entry; one 32-bit word of group bits per ray block");
+constexpr uint32_t kMGroups = kMTile / 4u;        // 128 groups of four
+constexpr uint32_t kMBlocks = kMTile / 32u;       // 16 fragments
+constexpr uint32_t kMWords = (kMBlocks * 4u + 31u) / 32u;     // 32-bit words of group bits per ray block and tile (4 bits per fragment)
+constexpr uint32_t kMRecQ = kMGroups * 8u;        // 1024 float4: the f32 part
+constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 2048 float4 = 32 KB
+static_assert(kMThreads % 64u == 0u && kMThreads <= 1024u, "whole waves");
+static_assert(kMTileQ % kMThreads == 0u, "whole workgroup LDS-DMA passes");
+static_assert(kMGroups <= 128u, "7-bit group index in a list entry");
 static_assert(kMBlocks * 2u <= kMGroups, "the Hmax table fits chunk 7");
 SP_DEV constexpr uint32_t cylm_slot(uint32_t group, uint32_t chunk) { return chunk * kMGroups + group; }
 // scaled Hmax of the four groups 8 tb + 2 j + hh (j = 0..3) that lane half hh owns in fragment tb: component j of this float4
@@ -107,22 +117,64 @@ SP_DEV void cylm_store(float4* __restrict__ tile, uint32_t in_tile, const float4
 	frag[0] = k0; frag[32] = k1;
 }
 
-// ---- prepass 1: sort key of every triangle = class (2 bits) | float bits of H >> 2 (H >= 0 or +inf: the bits order like the
-// values), value = the triangle's index; triangles per class -> hdr[0..2] (zeroed by the host)
-__global__ void __launch_bounds__(256) k_cylm_keys(const float* __restrict__ tris, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                  uint32_t* __restrict__ hdr) {
+// ---- The "big" class.  A triangle whose cylinder is a sizeable fraction of the scene (walls, floors, ground planes) survives stage 1
+// for practically every ray: the filter, its list entry, the f32 re-test and the gather of its exact record are pure overhead on it.
+// Such triangles -- at most kMBig of them, cylinder radius H >= S / 64 (S = the scene's length scale), the threshold rising in steps
+// of 4 while more than kMBig qualify, none at all if even H >= S does not get below that -- are taken out of the stream: every lane
+// runs the reference's test on them for its own ray at the start of a scan, the records arriving through the scalar cache
+// (cpu_renderer.cpp:39-49 visits them like any other triangle; the order is immaterial, sp_cyl_scan.h).
+constexpr uint32_t kMBig = 64u;
+constexpr int kMBigLevels = 4;                      // H / S >= 2^-6, 2^-4, 2^-2, 2^0
+
+SP_DEV int cylm_big_level(float H, float S) {       // the highest level the triangle reaches, -1: none (or a degenerate record: H = +inf stays in the stream)
+	if (!(S > 0.0f) || !(H < __builtin_inff())) return -1;
+	const float r = H / S;
+	return r >= 1.0f ? 3 : r >= 0.25f ? 2 : r >= 0.0625f ? 1 : r >= 0.015625f ? 0 : -1;
+}
+
+// ---- prepass 0: how many triangles reach each level -> hdr[9 .. 12] (zeroed by the host)
+__global__ void __launch_bounds__(256) k_cylm_count_big(const float* __restrict__ tris, uint32_t n, const unsigned int* __restrict__ bounds, uint32_t* __restrict__ hdr) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const float S = cylm_scale(__uint_as_float(bounds[0]));
+	int lvl = -1;
+	if (i < n) {
+		float4 q0, q1;
+		(void)cyl_record(tris + (size_t)i * 12, i, q0, q1);
+		lvl = cylm_big_level(q1.y, S);
+	}
+#pragma unroll
+	for (int k = 0; k < kMBigLevels; ++k) {
+		const int cnt = __syncthreads_count(lvl >= k);
+		if (threadIdx.x == 0 && cnt) atomicAdd(hdr + 9 + k, (uint32_t)cnt);
+	}
+}
+
+// the level from which on triangles are "big" in this scene: the lowest one that at most kMBig triangles reach (kMBigLevels: none)
+SP_DEV int cylm_big_threshold(const uint32_t* __restrict__ hdr) {
+	for (int k = 0; k < kMBigLevels; ++k) if (hdr[9 + k] <= kMBig) return k;
+	return kMBigLevels;
+}
+
+// ---- prepass 1: sort key of every triangle = class (2 bits; 3 = big) | float bits of H >> 2 (H >= 0 or +inf: the bits order like the
+// values), value = the triangle's index; triangles per class -> hdr[0..2], big ones -> hdr[8] (zeroed by the host)
+__global__ void __launch_bounds__(256) k_cylm_keys(const float* __restrict__ tris, uint32_t n, const unsigned int* __restrict__ bounds, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals, uint32_t* __restrict__ hdr) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const float S = cylm_scale(__uint_as_float(bounds[0]));
+	const int thr = cylm_big_threshold(hdr);
 	int cls = -1;
 	if (i < n) {
 		float4 q0, q1;
 		cls = cyl_record(tris + (size_t)i * 12, i, q0, q1);
+		const int lvl = cylm_big_level(q1.y, S);
+		if (lvl >= 0 && lvl >= thr) cls = 3;
 		keys[i] = ((uint32_t)cls << 30) | (__float_as_uint(q1.y) >> 2);
 		vals[i] = i;
 	}
 #pragma unroll
-	for (int k = 0; k < 3; ++k) {
+	for (int k = 0; k < 4; ++k) {
 		const int cnt = __syncthreads_count(cls == k);
-		if (threadIdx.x == 0 && cnt) atomicAdd(hdr + k, (uint32_t)cnt);
+		if (threadIdx.x == 0 && cnt) atomicAdd(hdr + (k < 3 ? k : 8), (uint32_t)cnt);
 	}
 }
 
@@ -136,12 +188,22 @@ __global__ void k_cylm_hdr(uint32_t* __restrict__ hdr, const unsigned int* __res
 
 // ---- prepass 3: the triangle at sorted position p (classes in order, ascending H within a class; equal keys in index order:
 // the sort is stable) goes to rank p - (start of its class) of the class's run of tiles
+// The big class (the last hdr[8] places of the sorted order) goes to `big`: the exact record of k_repack (v0, e1, e2) with the
+// triangle's index in the unused second word of its third float4.
 __global__ void __launch_bounds__(256) k_cylm_scatter(const float* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ sorted,
-                                                     const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
+                                                     const uint32_t* __restrict__ hdr, float4* __restrict__ rec, const float4* __restrict__ scan, float4* __restrict__ big) {
 	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
 	if (p >= n) return;
 	const uint32_t i = sorted[p];
 	const float S = ((const float*)hdr)[7];
+	const uint32_t n_stream = hdr[0] + hdr[1] + hdr[2];
+	if (p >= n_stream) {
+		const uint32_t b = p - n_stream;
+		const float4 x2 = scan[3 * (size_t)i + 2];
+		big[3 * b + 0] = scan[3 * (size_t)i + 0]; big[3 * b + 1] = scan[3 * (size_t)i + 1];
+		big[3 * b + 2] = make_float4(x2.x, __uint_as_float(i), 0.0f, 0.0f);
+		return;
+	}
 	float4 q0, q1;
 	const int cls = cyl_record(tris + (size_t)i * 12, i, q0, q1);
 	const uint32_t c0 = cls == 0 ? 0u : cls == 1 ? hdr[0] : hdr[0] + hdr[1];
@@ -166,7 +228,7 @@ __global__ void __launch_bounds__(256) k_cylm_pad(const uint32_t* __restrict__ h
 
 // ---- prepass 5: Hmax^ = 256 max(H) / S of every group (one thread per group, one block per tile): +inf if the group holds a
 // degenerate triangle (always survives), -inf if it holds nothing but padding (never does)
-__global__ void __launch_bounds__(64) k_cylm_hmax(const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
+__global__ void __launch_bounds__(kMGroups) k_cylm_hmax(const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
 	if (blockIdx.x >= hdr[6] || threadIdx.x >= kMGroups) return;
 	float4* tile = rec + (size_t)blockIdx.x * kMTileQ;
 	const uint32_t grp = threadIdx.x, tb = grp >> 3, j = (grp & 7u) >> 1, hh = grp & 1u;
@@ -181,8 +243,8 @@ SP_DEV void cylm_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t 
 	typedef __attribute__((address_space(1))) const void* gptr_t;
 	typedef __attribute__((address_space(3))) void* lptr_t;
 #pragma unroll
-	for (int p = 0; p < (int)(kMTileQ / 256u); ++p)
-		__builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + tid), (lptr_t)(dst + p * 256 + wbase), 16, 0, 0);
+	for (int p = 0; p < (int)(kMTileQ / kMThreads); ++p)
+		__builtin_amdgcn_global_load_lds((gptr_t)(src + p * kMThreads + tid), (lptr_t)(dst + p * kMThreads + wbase), 16, 0, 0);
 }
 
 struct CylmGroup { float4 q0[4]; float4 mh01, mh23; };
@@ -227,6 +289,7 @@ __global__ void __launch_bounds__(64) k_selftest_cylm(const float* __restrict__ 
 // an s_waitcnt vmcnt(0) behind it -- a round trip to L2 per tile, and a wait for the LDS-DMA in flight as well (vmcnt counts in order)
 struct CylmHdr {
 	uint32_t n0, n1, n2, f1, f2, tiles;      // triangles per class; first tile of classes 1 and 2 (class 0 starts at tile 0); tiles in all
+	uint32_t nbig;                           // triangles of the big class (outside the stream)
 	float S;
 	// the class being scanned (scalars on purpose: an array indexed by the class number ends up in scratch memory, and a scratch
 	// load waits on vmcnt like any other)
@@ -237,6 +300,7 @@ struct CylmHdr {
 		f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[4]); f2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[5]);
 		tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[6]);
 		S = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[7]));
+		nbig = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[8]);
 		cls = 0u; cn = n0; cfirst = 0u; cend = f1;
 	}
 	// tile gt lies beyond the current class: move on (true), at most twice per tile (an empty class 1)
@@ -375,10 +439,10 @@ SP_DEV uint32_t cylm_bits(const float16v& g, const float4 Hm, float Dn, float Dq
 // block) is issued before the 20 VALU instructions that turn the previous result into bits, and the LDS reads run a fragment
 // ahead -- an in-order wave otherwise sits through the LDS latency, both matrix instructions and their result latency before its
 // first VALU instruction of every fragment.  No extra accumulators: a ray block's 16 registers are free again when its bits are out.
-SP_DEV void cylm_stage1(const float4* cur, uint32_t nblk, uint32_t lane, const CylmRay& R, uint32_t (&word)[2]) {
+SP_DEV void cylm_stage1(const float4* cur, uint32_t tb0, uint32_t nblk, uint32_t lane, const CylmRay& R, uint32_t (&word)[2]) {
 	if (nblk == 0u) return;
-	const half8* frags = (const half8*)(cur + kMRecQ) + lane;
-	const float4* hmq = cur + cylm_hmq(0u, lane >> 5);
+	const half8* frags = (const half8*)(cur + kMRecQ) + tb0 * 64u + lane;
+	const float4* hmq = cur + cylm_hmq(tb0, lane >> 5);
 	float16v zero;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
@@ -403,7 +467,7 @@ SP_DEV void cylm_stage1(const float4* cur, uint32_t nblk, uint32_t lane, const C
 	word[1] = cylm_bits(g1, Hm, R.Dn[1], R.Dqn[1], word[1]);
 }
 
-constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: ray << 6 | group); what does not fit waits for the next pass
+constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: ray << 7 | group); what does not fit waits for the next pass
 constexpr uint32_t kMQ2 = 128u;              // exact-test candidates a wave can hold (32 bits each: ray << 26 | triangle index)
 constexpr uint32_t kMIdxBits = 26u;          // hence at most 2^26 - 1 triangles for this scan (the host picks another one beyond)
 
@@ -435,9 +499,9 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 	// s_waitcnt vmcnt(0), can tell these apart -- the transfer has the whole tile to land in, not just stage 2
 	__shared__ float4 sm0[kMTileQ];
 	__shared__ float4 sm1[kMTileQ];
-	__shared__ unsigned short lst[4 * kMCap];
-	__shared__ uint32_t q2[4 * kMQ2];
-	__shared__ unsigned long long cell[256];
+	__shared__ unsigned short lst[kMWaves * kMCap];
+	__shared__ uint32_t q2[kMWaves * kMQ2];
+	__shared__ unsigned long long cell[kMThreads];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u, hh = lane >> 5;
 	unsigned short* const mylst = lst + (tid >> 6) * kMCap;
 	uint32_t* const myq2 = q2 + (tid >> 6) * kMQ2;
@@ -448,13 +512,32 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 	R.setup(rv, hd.S, s);
 	CylRay<1>& f = R.f;
 
-	const unsigned long long kNone = ((unsigned long long)__float_as_uint(kMaxDist) << 32) | 0xffffffffull;
-	cell[tid] = kNone;
+	// ---- the big class first: every lane, its own ray, records through the scalar cache (wave-uniform addresses)
+	{
+		float bd0 = kMaxDist; int bi0 = -1;
+		typedef float f4v __attribute__((ext_vector_type(4)));
+		typedef __attribute__((address_space(4))) const f4v* cptr_t;             // constant address space: a uniform load is a scalar load
+		const cptr_t big = (cptr_t)(uintptr_t)cs.big;
+		for (uint32_t b = 0; b < hd.nbig; ++b) {
+			const f4v x0 = big[3 * b + 0], x1 = big[3 * b + 1], x2 = big[3 * b + 2];
+			const int idx = (int)__float_as_uint(x2.y);
+			const float d = ray_tri_strict(s.o[0], s.dir[0], mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
+			// the (d, index) minimum: cpu_renderer.cpp:44's "first strictly smaller d wins" over ascending indices
+			const bool take = (d > 0.0f) && (idx != s.src[0]) && ((d < bd0) || (d == bd0 && idx < bi0));
+			bd0 = take ? d : bd0;
+			bi0 = take ? idx : bi0;
+		}
+		cell[tid] = ((unsigned long long)__float_as_uint(bd0) << 32) | (unsigned long long)(uint32_t)bi0;     // bi0 = -1: the "no hit" key
+	}
 	R.build(0u, lane);
 
 	// ---- step (b): exact tests of the top n (<= 64) candidates of the stack; wave-uniform n
 	uint32_t q2n = 0;                                     // candidates on the stack (wave-uniform)
 	auto exact_batch = [&](uint32_t n) {
+#ifdef SP_EXP_NO_EXACT          // timing experiment only (wrong images): the candidates are counted and dropped
+		q2n -= n;
+		return;
+#endif
 		const bool ok = lane < n;
 		// idle lanes (only in the last batch of a scan): their own ray against the zero record behind the last triangle
 		const uint32_t e = ok ? myq2[q2n - n + lane] : ((lane << kMIdxBits) | a.n_tris);
@@ -503,48 +586,54 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			R.build(hd.cls, lane);
 		}
 		const uint32_t nblk = hd.fragments(gt);
-		// ---- stage 1: word[rb] gets 4 bits per fragment (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
-		uint32_t word[2] = { 0u, 0u };
-#ifdef SP_CYLM_NO_PIPELINE
-		for (uint32_t tb = 0; tb < nblk; ++tb) cylm_fragment(cur, tb, lane, R, word);
-#else
-		cylm_stage1(cur, nblk, lane, R, word);
-#endif
-		const uint32_t done = nblk * 4u;                              // bits appended; left-align
+		// ---- stage 1: word[w][rb] gets 4 bits per fragment 8 w + f (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
+		uint32_t word[kMWords][2];
 #pragma unroll
-		for (int rb = 0; rb < 2; ++rb) word[rb] = done == 0u ? 0u : (word[rb] << (32u - done));
+		for (int w = 0; w < (int)kMWords; ++w) {
+			word[w][0] = word[w][1] = 0u;
+			const uint32_t tb0 = 8u * (uint32_t)w;
+			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < 8u ? nblk - tb0 : 8u) : 0u;       // fragments of this word (wave-uniform)
+			cylm_stage1(cur, tb0, nb, lane, R, word[w]);
+			const uint32_t done = nb * 4u;                            // bits appended; left-align
+#pragma unroll
+			for (int rb = 0; rb < 2; ++rb) word[w][rb] = done == 0u ? 0u : (word[w][rb] << (32u - done));
 #ifdef SP_DBG_ALLBITS
-		word[0] = word[1] = done == 0u ? 0u : (0xffffffffu << (32u - done));
+			word[w][0] = word[w][1] = done == 0u ? 0u : (0xffffffffu << (32u - done));
 #endif
+		}
 		SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_s1, ph_t0, ph_t1);
 #ifdef SP_CYLM_LATE_DMA
 		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, nxt, tid, wbase);
 #endif
 		// ---- stage 2 (a): one list per wave; entry = (ray = donor lane) << 6 | group
 #ifdef SP_EXP_NO_STAGE2
-		exp_acc ^= word[0] ^ word[1];
+		for (int w = 0; w < (int)kMWords; ++w) exp_acc ^= word[w][0] ^ word[w][1];
 		for (; false;) {
 #else
 		for (;;) {
 #endif
-			const uint32_t c = (uint32_t)__builtin_popcount(word[0]) + (uint32_t)__builtin_popcount(word[1]);
+			uint32_t c = 0;
+#pragma unroll
+			for (int w = 0; w < (int)kMWords; ++w) c += (uint32_t)__builtin_popcount(word[w][0]) + (uint32_t)__builtin_popcount(word[w][1]);
 			const uint32_t incl = wave_incl_scan(c);
 			const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			if (all == 0u) break;
 			uint32_t j = incl - c;
 			const uint32_t jend = incl < kMCap ? incl : kMCap;            // what does not fit stays in the words for the next pass
 #pragma unroll
+			for (int w = 0; w < (int)kMWords; ++w)
+#pragma unroll
 			for (int rb = 0; rb < 2; ++rb) {
-				uint32_t m = word[rb];
+				uint32_t m = word[w][rb];
 				const uint32_t ray = (lane & 31u) + 32u * (uint32_t)rb;
 				while (__any(m != 0u && j < jend)) {
 					if (m != 0u && j < jend) {
-						const uint32_t e = (uint32_t)__builtin_clz(m);                      // e-th appended bit: fragment e / 4, j = e % 4
-						mylst[j++] = (unsigned short)((ray << 6) | ((e >> 2) * 8u + 2u * (e & 3u) + hh));
+						const uint32_t e = (uint32_t)__builtin_clz(m);                      // e-th appended bit of word w: fragment 8 w + e / 4, j = e % 4
+						mylst[j++] = (unsigned short)((ray << 7) | (64u * (uint32_t)w + 2u * e + hh));     // group 8 tb + 2 j + hh = 64 w + 2 e + hh
 						m &= ~(0x80000000u >> e);
 					}
 				}
-				word[rb] = m;
+				word[w][rb] = m;
 			}
 			__builtin_amdgcn_wave_barrier();                             // every lane's entries are issued before the list is read back (one wave: LDS operations complete in order)
 			const uint32_t total = all < kMCap ? all : kMCap;
@@ -555,9 +644,9 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t ent = base + lane;
 				const bool ok = ent < total;
-				const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 6);
-				const int L = (int)(entry >> 6);
-				const uint32_t grp = entry & 63u;
+				const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 7);
+				const int L = (int)(entry >> 7);
+				const uint32_t grp = entry & 127u;
 				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
 				const float Pa = __shfl(f.Pa[0], L, 64), Pb = __shfl(f.Pb[0], L, 64), Pc = __shfl(f.Pc[0], L, 64);
 				const float D = __shfl(f.D[0], L, 64), Dq = __shfl(f.Dq[0], L, 64);
@@ -591,7 +680,11 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			SP_PH_STAMP(ph_t1);
 		}
 		// full batches now rather than later: the exact turns overlap the arrival of the next tile
+#ifdef SP_EXP_DRAIN_ALL      // experiment: every wave empties its stack at the end of every tile (same number of exact turns for the waves of a workgroup)
+		while (q2n) exact_batch(q2n < 64u ? q2n : 64u);
+#else
 		while (q2n >= 64u) exact_batch(64u);
+#endif
 #ifdef SP_FILTER_STATS
 		if (lane == 0) atomicAdd(a.scans + 3, 1ull);
 #endif
@@ -620,12 +713,13 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 }
 
 // ---- test-only (sphip_selftest_stage1): stage 1 ALONE, exactly as scan_cylm runs it (same ray setup, same fragment function,
-// same tiles), for 64 rays per one-wave workgroup (n_rays a multiple of 64).  out_words[((block * 64 + lane) * tiles + tile) * 2 + rb] = the lane's word:
-// bit 31 - (4 tb + j) = group 8 tb + 2 j + (lane >> 5) of that tile survives for ray 64 block + (lane & 31) + 32 rb.
+// same tiles), for 64 rays per one-wave workgroup (n_rays a multiple of 64).  T = kMTile triangles per tile, W = kMWords words per ray block.
+// out_words[(((block * 64 + lane) * tiles + tile) * 2 + rb) * W + w] = the lane's word w: bit 31 - (4 f + j) = group 8 (8 w + f) + 2 j + (lane >> 5)
+// of that tile survives for ray 64 block + (lane & 31) + 32 rb.
 // out_tri (optional): the same side products g tested PER TRIANGLE with the triangle's own scaled H (x = fma(-H^, D^, |g|), sign(x - Dq^)):
-// out_tri[(((block * 64 + lane) * tiles + tile) * 2 + rb) * 4 + tb / 2], bit 31 - (16 (tb & 1) + 4 j + i) = triangle 32 tb + 8 j + 4 (lane >> 5) + i.
+// out_tri[(((block * 64 + lane) * tiles + tile) * 2 + rb) * (T / 64) + tb / 2], bit 31 - (16 (tb & 1) + 4 j + i) = triangle 32 tb + 8 j + 4 (lane >> 5) + i.
 // A group bit may be set where none of its triangle bits is (the group bound is weaker), never the other way round.
-// Block 0 also writes the stream order: out_order[tile * kMTile + 4 group + u] = triangle index at that place (n_tris = padding).
+// Block 0 also writes the stream order: out_order[tile * T + 4 group + u] = triangle index at that place (n_tris = padding).
 __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict__ rays, uint32_t n_rays, const CylStream cs, const unsigned int* __restrict__ bounds,
                                                       uint32_t* __restrict__ out_words, uint32_t* __restrict__ out_tri, int* __restrict__ out_order) {
 	__shared__ float4 sm[kMTileQ];
@@ -648,11 +742,16 @@ __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict_
 		for (uint32_t q = lane; q < kMTileQ; q += 64u) sm[q] = cs.rec[(size_t)gt * kMTileQ + q];
 		__syncthreads();
 		const uint32_t nblk = hd.fragments(gt);
-		uint32_t word[2] = { 0u, 0u };
-		cylm_stage1(sm, nblk, lane, R, word);
-		const uint32_t done = nblk * 4u;
+		for (uint32_t w = 0; w < kMWords; ++w) {
+			uint32_t word[2] = { 0u, 0u };
+			const uint32_t tb0 = 8u * w;
+			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < 8u ? nblk - tb0 : 8u) : 0u;
+			cylm_stage1(sm, tb0, nb, lane, R, word);
+			const uint32_t done = nb * 4u;
 #pragma unroll
-		for (int rb = 0; rb < 2; ++rb) if (k < n_rays) out_words[((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb] = done == 0u ? 0u : (word[rb] << (32u - done));
+			for (int rb = 0; rb < 2; ++rb)
+				if (k < n_rays) out_words[(((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb) * kMWords + w] = done == 0u ? 0u : (word[rb] << (32u - done));
+		}
 		if (out_tri) {
 			float16v zero;
 #pragma unroll
@@ -678,7 +777,7 @@ __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict_
 					}
 					// two fragments per output word: even fragment in the high half
 					if (k < n_rays) {
-						uint32_t* o = out_tri + (((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb) * 4u + (tb >> 1);
+						uint32_t* o = out_tri + (((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb) * (kMTile / 64u) + (tb >> 1);
 						if (tb >= nblk) w = 0u;
 						if ((tb & 1u) == 0u) *o = w << 16; else *o |= (w & 0xffffu);
 					}
@@ -686,11 +785,15 @@ __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict_
 			}
 		}
 		if (blockIdx.x == 0) {
-			const float4 gi = sm[cylm_slot(lane, 6u)];
-			int* o = out_order + (size_t)gt * kMTile + 4u * lane;
-			o[0] = (int)__float_as_uint(gi.x); o[1] = (int)__float_as_uint(gi.y); o[2] = (int)__float_as_uint(gi.z); o[3] = (int)__float_as_uint(gi.w);
+			for (uint32_t grp = lane; grp < kMGroups; grp += 64u) {
+				const float4 gi = sm[cylm_slot(grp, 6u)];
+				int* o = out_order + (size_t)gt * kMTile + 4u * grp;
+				o[0] = (int)__float_as_uint(gi.x); o[1] = (int)__float_as_uint(gi.y); o[2] = (int)__float_as_uint(gi.z); o[3] = (int)__float_as_uint(gi.w);
+			}
 		}
 	}
 }
 
-} // namespace sp
+} } // namespace sp::SP_CYLM_NS
+#undef SP_PH_STAMP
+#undef SP_PH_ADD

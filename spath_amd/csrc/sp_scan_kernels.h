@@ -1,24 +1,29 @@
 // Kernels over the two-stage scans: the closest-hit scan alone, renderer::render_flat, renderer::render.
 // SCAN = 0: sp_filter_scan.h (slab filter, per-lane LDS queues)     SCAN = 1: sp_cyl_scan.h (cylinder filter, bit words, stage 2 per lane)
 // SCAN = 2: sp_cyl_scan.h scan_cylw (the same stage 1, stage 2 shared by the wave)
-// SCAN = 3: sp_cylm_scan.h scan_cylm (stage 1 on the f16 matrix pipe, one ray per lane, stage 2 shared by the wave)
+// SCAN = 3: sp_cylm_scan.h scan_cylm (stage 1 on the f16 matrix pipe, one ray per lane, stage 2 shared by the wave), 256-thread workgroups
+// SCAN = 4: the same scan in 512-thread workgroups with 512-triangle tiles (larger scenes)
 #pragma once
 
 #include "sp_filter_scan.h"
 #include "sp_cyl_scan.h"
-#include "sp_cylm_scan.h"
+#include "sp_cylm_both.h"
 
 namespace sp {
 
 struct ScanSrc {
 	const float4* filt;      // slab records (k_repack_filter)
 	CylStream cyl;           // cylinder records (k_cyl_scatter)
-	CylStream cylm;          // cylinder records + matrix fragments (k_cylm_scatter)
+	CylStream cylm;          // cylinder records + matrix fragments (k_cylm_scatter), in the tile size of the scan that reads them
 };
+
+// threads per workgroup of the kernels below: the matrix-pipe scan shares its (larger) tiles between 8 waves
+template <int SCAN> constexpr uint32_t scan_block() { return SCAN == 4 ? cylm512::kMThreads : 256u; }
 
 template <int R, int SCAN>
 SP_DEV void two_stage_scan(const KArgs& a, const ScanSrc& src, float rv, const RaySlots<R>& s, float (&bd)[R], int (&bi)[R]) {
-	if constexpr (SCAN == 3) { static_assert(R == 1, "scan_cylm: one ray per lane"); scan_cylm(a, src.cylm, rv, s, bd, bi); }
+	if constexpr (SCAN == 4) { static_assert(R == 1, "scan_cylm: one ray per lane"); cylm512::scan_cylm(a, src.cylm, rv, s, bd, bi); }
+	else if constexpr (SCAN == 3) { static_assert(R == 1, "scan_cylm: one ray per lane"); cylm256::scan_cylm(a, src.cylm, rv, s, bd, bi); }
 	else if constexpr (SCAN == 2) scan_cylw<R>(a, src.cyl, rv, s, bd, bi);
 	else if constexpr (SCAN == 1) scan_cyl<R>(a, src.cyl, rv, s, bd, bi);
 	else scan_filter<R>(a, src.filt, rv, s, bd, bi);
@@ -26,14 +31,14 @@ SP_DEV void two_stage_scan(const KArgs& a, const ScanSrc& src, float rv, const R
 
 // ---- the closest-hit scan alone with a two-stage scan; R rays per lane
 template <int R, int SCAN>
-__global__ void __launch_bounds__(256, SP_PT_WAVES) k_hit_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds,
+__global__ void __launch_bounds__(scan_block<SCAN>(), SP_PT_WAVES) k_hit_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds,
                                                     const int* __restrict__ src_idx, int* __restrict__ out_idx, float* __restrict__ out_d) {
 	const float rv = __uint_as_float(bounds[0]);
 	RaySlots<R> s;
 	uint32_t k[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		k[r] = blockIdx.x * (256u * R) + r * 256u + threadIdx.x;
+		k[r] = blockIdx.x * (scan_block<SCAN>() * R) + r * scan_block<SCAN>() + threadIdx.x;
 		const bool valid = k[r] < a.n_rays;
 		const uint32_t kk = valid ? k[r] : a.n_rays - 1;
 		const float* p = a.rays + (size_t)kk * 6;
@@ -50,7 +55,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_hit_filter(const KArgs a, 
 
 // ---- renderer::render_flat with a two-stage scan; R pixels per lane
 template <int R, int SCAN>
-__global__ void __launch_bounds__(256, SP_PT_WAVES) k_flat_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds) {
+__global__ void __launch_bounds__(scan_block<SCAN>(), SP_PT_WAVES) k_flat_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds) {
 	const float rv = __uint_as_float(bounds[0]);
 	const uint32_t tid = threadIdx.x;
 	RaySlots<R> s;
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_flat_filter(const KArgs a,
 	bool valid[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		k[r] = blockIdx.x * (256u * R) + r * 256u + tid;
+		k[r] = blockIdx.x * (scan_block<SCAN>() * R) + r * scan_block<SCAN>() + tid;
 		valid[r] = k[r] < a.n_rays;
 		const uint32_t kk = valid[r] ? k[r] : a.n_rays - 1;
 		const float* p = a.rays + (size_t)kk * 6;
@@ -90,16 +95,17 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_flat_filter(const KArgs a,
 // touched once per bounce, against ~10^5 VALU instructions per bounce.
 //   work layout: hist[depth][k] = {idx, cos bits} (8 B), then acc[c][k] (3 floats), k < n_work
 template <int R, bool SPLIT, int SCAN>
-__global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds,
+__global__ void __launch_bounds__(scan_block<SCAN>(), SP_PT_WAVES) k_pt_filter(const KArgs a, const ScanSrc src2, const unsigned int* __restrict__ bounds,
                                                    int2* __restrict__ hist, float* __restrict__ acc, uint32_t n_work) {
 	const float rv = __uint_as_float(bounds[0]);
 	const uint32_t tid = threadIdx.x;
-	const uint32_t k0 = blockIdx.x * (256u * R) + tid;       // work-buffer slot of path r: k0 + r*256
-	const uint32_t kstep = SPLIT ? 0u : 256u;                // ray index of slot r: kr0 + r*kstep
+	constexpr uint32_t B = scan_block<SCAN>();                // threads per workgroup
+	const uint32_t k0 = blockIdx.x * (B * R) + tid;          // work-buffer slot of path r: k0 + r*B
+	const uint32_t kstep = SPLIT ? 0u : B;                   // ray index of slot r: kr0 + r*kstep
 	const bool chunked = a.n_chunks > 1;                     // blockIdx = chunk * px_blocks + pixel block
 	const uint32_t pblk = chunked ? blockIdx.x % a.px_blocks : blockIdx.x;
 	const uint32_t chunk = chunked ? blockIdx.x / a.px_blocks : 0u;
-	const uint32_t kr0 = SPLIT ? pblk * 256u + tid : pblk * (256u * R) + tid;
+	const uint32_t kr0 = SPLIT ? pblk * B + tid : pblk * (B * R) + tid;
 	uint32_t pixel[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
@@ -107,7 +113,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 		const uint32_t kk = k < a.n_rays ? k : a.n_rays - 1;
 		pixel[r] = (uint32_t)shard_pixel(a, kk);
 #pragma unroll
-		for (int c = 0; c < 3; ++c) acc[(size_t)c * n_work + k0 + r * 256u] = 0.0f;
+		for (int c = 0; c < 3; ++c) acc[(size_t)c * n_work + k0 + r * B] = 0.0f;
 	}
 	// primary-hit reuse: cpu_renderer.cpp:74-76 starts every sample from the same vp.rays[idx], so the first
 	// scan of all samples of a pixel has one result; the host ran it once per pixel (k_hit_filter) before this launch
@@ -173,7 +179,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 					s.o[r] = add3(s.o[r], scale3(s.dir[r], bd[r]));
 					s.dir[r] = nd;
 					s.src[r] = bi[r];
-					hist[(size_t)depth * n_work + k0 + r * 256u] = make_int2(bi[r], (int)__float_as_uint(ct));
+					hist[(size_t)depth * n_work + k0 + r * B] = make_int2(bi[r], (int)__float_as_uint(ct));
 					nh[r] = depth + 1;
 				}
 				s.act[r] = hit;
@@ -181,7 +187,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 		}
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
-			const uint32_t kw = k0 + r * 256u;
+			const uint32_t kw = k0 + r * B;
 			f3 rec = mk3(0.0f, 0.0f, 0.0f);
 			for (int d = nh[r] - 1; d >= 0; --d) {
 				const int2 hc = hist[(size_t)d * n_work + kw];
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(256, SP_PT_WAVES) k_pt_filter(const KArgs a, c
 #pragma unroll
 	for (int r = 0; r < (SPLIT ? 1 : R); ++r) {
 		const uint32_t k = kr0 + r * kstep;
-		const uint32_t kw = k0 + r * 256u;
+		const uint32_t kw = k0 + r * B;
 		if (k < a.n_rays && !chunked) {
 			const f3 av = scale3(mk3(acc[kw], acc[(size_t)n_work + kw], acc[(size_t)2 * n_work + kw]), a.inv_n);
 			a.out_rgba[k] = vec3_rgba(mk3(clamp01(av.x), clamp01(av.y), clamp01(av.z)));

@@ -41,9 +41,10 @@ struct sphip_ctx {
 	int device = 0;
 	hipStream_t own_stream = nullptr;       // host-pointer path
 	hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_u0 = nullptr, ev_u1 = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;
-	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, sort_kv, sort_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim, cylm_rec, cylm_hdr;
+	DevBuf tris, mats, scan, filt, bounds, samp, rays, rgba, accum, counter, work, bvh_nodes, bvh_rec, bvh_idx, sort_kv, sort_hist, bvh_meta, cyl_rec, cyl_cnt, cyl_hdr, prim, cylm_rec, cylm_hdr, cylm_big;
 	// record streams beyond the exact one are derived from `tris` the first time a kernel variant that reads them runs on the scene
 	bool bvh_valid = false, filt_valid = false, cyl_valid = false, cylm_valid = false;
+	bool cylm_wide = false;                 // the stream in cylm_rec is laid out for the 512-thread shape of the default scan (sp_cylm_both.h)
 	uint32_t bvh_leaves = 0;
 	size_t n_tris = 0;
 	bool have_scene = false;
@@ -168,28 +169,54 @@ int radix_sort(sphip_ctx* c, uint32_t n, uint32_t key_bits, hipStream_t st, int*
 }
 
 // ---- the default scan's stream (sp_cylm_scan.h): classes by dominant axis, ascending cylinder radius within a class (device sort),
-// 256-triangle tiles of f32 records + f16 matrix fragments + the per-group Hmax table
-int ensure_cylm(sphip_ctx* c, hipStream_t st) {
-	if (c->cylm_valid) return SPHIP_OK;
-	const uint32_t n = (uint32_t)c->n_tris, nblocks = (n + 255) / 256, max_tiles = n / sp::kMTile + 4;
+// tiles of kMTile triangles: f32 records + f16 matrix fragments + the per-group Hmax table
+template <bool WIDE>
+int build_cylm(sphip_ctx* c, hipStream_t st) {
+#define SP_CM(x) (WIDE ? sp::cylm512::x : sp::cylm256::x)
+	const uint32_t n = (uint32_t)c->n_tris, nblocks = (n + 255) / 256, max_tiles = n / SP_CM(kMTile) + 4;
 	int rc;
-	if ((rc = ensure(c, c->sort_kv, (size_t)n * 16)) || (rc = ensure(c, c->cylm_hdr, 256)) ||
-	    (rc = ensure(c, c->cylm_rec, (size_t)max_tiles * sp::kMTileQ * 16))) return rc;
+	if ((rc = ensure(c, c->sort_kv, (size_t)n * 16)) || (rc = ensure(c, c->cylm_hdr, 256)) || (rc = ensure(c, c->cylm_big, sp::cylm256::kMBig * 48)) ||
+	    (rc = ensure(c, c->cylm_rec, (size_t)max_tiles * SP_CM(kMTileQ) * 16))) return rc;
 	uint32_t* keys = (uint32_t*)c->sort_kv.p;
 	uint32_t* vals = (uint32_t*)c->sort_kv.p + (size_t)2 * n;
 	uint32_t* hdr = (uint32_t*)c->cylm_hdr.p;
+	const float* tris = (const float*)c->tris.p;
+	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
+	float4* rec = (float4*)c->cylm_rec.p;
 	HIP_TRY(c, hipMemsetAsync(hdr, 0, 256, st));
-	hipLaunchKernelGGL(sp::k_cylm_keys, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, keys, vals, hdr);
+	// (the class, key and big-class kernels do not depend on the tile size)
+	hipLaunchKernelGGL(sp::cylm256::k_cylm_count_big, dim3(nblocks), dim3(256), 0, st, tris, n, bnd, hdr);
+	hipLaunchKernelGGL(sp::cylm256::k_cylm_keys, dim3(nblocks), dim3(256), 0, st, tris, n, bnd, keys, vals, hdr);
 	int half = 0;
 	if ((rc = radix_sort(c, n, 32, st, &half))) return rc;
-	hipLaunchKernelGGL(sp::k_cylm_hdr, dim3(1), dim3(1), 0, st, hdr, (const unsigned int*)c->bounds.p);
-	hipLaunchKernelGGL(sp::k_cylm_scatter, dim3(nblocks), dim3(256), 0, st, (const float*)c->tris.p, n, (const uint32_t*)(vals + (size_t)half * n),
-	                   (const uint32_t*)hdr, (float4*)c->cylm_rec.p);
-	hipLaunchKernelGGL(sp::k_cylm_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)hdr, n, (float4*)c->cylm_rec.p);
-	hipLaunchKernelGGL(sp::k_cylm_hmax, dim3(max_tiles), dim3(64), 0, st, (const uint32_t*)hdr, (float4*)c->cylm_rec.p);
+	const uint32_t* sorted = vals + (size_t)half * n;
+	if (WIDE) {
+		hipLaunchKernelGGL(sp::cylm512::k_cylm_hdr, dim3(1), dim3(1), 0, st, hdr, bnd);
+		hipLaunchKernelGGL(sp::cylm512::k_cylm_scatter, dim3(nblocks), dim3(256), 0, st, tris, n, sorted, (const uint32_t*)hdr, rec, (const float4*)c->scan.p, (float4*)c->cylm_big.p);
+		hipLaunchKernelGGL(sp::cylm512::k_cylm_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)hdr, n, rec);
+		hipLaunchKernelGGL(sp::cylm512::k_cylm_hmax, dim3(max_tiles), dim3(sp::cylm512::kMGroups), 0, st, (const uint32_t*)hdr, rec);
+	} else {
+		hipLaunchKernelGGL(sp::cylm256::k_cylm_hdr, dim3(1), dim3(1), 0, st, hdr, bnd);
+		hipLaunchKernelGGL(sp::cylm256::k_cylm_scatter, dim3(nblocks), dim3(256), 0, st, tris, n, sorted, (const uint32_t*)hdr, rec, (const float4*)c->scan.p, (float4*)c->cylm_big.p);
+		hipLaunchKernelGGL(sp::cylm256::k_cylm_pad, dim3(3), dim3(256), 0, st, (const uint32_t*)hdr, n, rec);
+		hipLaunchKernelGGL(sp::cylm256::k_cylm_hmax, dim3(max_tiles), dim3(sp::cylm256::kMGroups), 0, st, (const uint32_t*)hdr, rec);
+	}
+#undef SP_CM
 	HIP_TRY(c, hipGetLastError());
 	c->cylm_valid = true;
+	c->cylm_wide = WIDE;
 	return SPHIP_OK;
+}
+
+// which shape of the default scan serves this scene (SPATH_HIP_CYLM_SHAPE=256|512 overrides, for A/B runs)
+bool cylm_wants_wide(const sphip_ctx* c) {
+	if (const char* e = getenv("SPATH_HIP_CYLM_SHAPE")) return atoi(e) == 512;
+	return c->n_tris >= sp::kMBigSceneTris;
+}
+
+int ensure_cylm(sphip_ctx* c, hipStream_t st) {
+	if (c->cylm_valid) return SPHIP_OK;
+	return cylm_wants_wide(c) ? build_cylm<true>(c, st) : build_cylm<false>(c, st);
 }
 
 // ---- class-sorted f32 cylinder records (sp_cyl_scan.h): count per block -> offsets -> scatter -> pad, all on the device
@@ -304,13 +331,18 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	TwoStage ts{1, false, 0};
 	const bool is_ts = two_stage(variant, &ts);
 	const uint32_t slots = is_ts && ts.split ? (uint32_t)ts.R : 1u;                       // samples of one pixel per lane
-	const uint32_t rays_per_block = is_ts && !ts.split ? 256u * (uint32_t)ts.R : 256u;
+	// the record stream the variant reads, derived from the scene on first use
+	if (is_ts && ts.scan == 3 && (rc = ensure_cylm(c, st))) return rc;
+	if (is_ts && ts.scan == 3 && c->cylm_wide) ts.scan = 4;                               // the 512-thread shape of the same scan (sp_cylm_both.h)
+	const uint32_t bthreads = is_ts && ts.scan == 4 ? sp::cylm512::kMThreads : 256u;      // threads per workgroup of the variant's kernels
+	const uint32_t rays_per_block = is_ts && !ts.split ? bthreads * (uint32_t)ts.R : bthreads;
+	const uint64_t chunk_target = kChunkTargetBlocks * 256u / bthreads;                   // the same number of resident-wave rounds
 	if (mode == SPHIP_MODE_PT && is_ts) {
 		const uint64_t px_blocks = (n_rays + rays_per_block - 1) / rays_per_block;
 		const uint64_t n_iter = (n_samples + slots - 1) / slots;
 		const uint32_t forced = ((uint32_t)flags & SPHIP_FLAG_CHUNKS_MASK) >> SPHIP_FLAG_CHUNKS_SHIFT;
 		if (forced) chunks = forced;
-		else while (px_blocks * chunks < kChunkTargetBlocks && chunks < 128) chunks *= 2;
+		else while (px_blocks * chunks < chunk_target && chunks < 128) chunks *= 2;
 		if (chunks > n_iter) chunks = (uint32_t)n_iter;
 		const uint64_t samp_bytes = (uint64_t)n_samples * 12 * ((n_rays + 255) / 256 * 256);
 		if (chunks > 1 && !forced) {
@@ -336,10 +368,10 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 			a.samp = (float*)c->samp.p;
 		}
 	}
-	const dim3 block(256);
-	const dim3 grid((unsigned)((n_rays + 255) / 256 * chunks));                           // exact-only kernels, accel, split variants, R = 1
+	const dim3 block(256), block_ts(bthreads);
+	const dim3 grid((unsigned)((n_rays + 255) / 256 * chunks));                           // exact-only kernels, accel
 	// one-scan modes (flat pass, hits) have no samples to share a lane: a split variant runs there with R pixels per lane
-	const uint32_t rpb1 = is_ts ? 256u * (uint32_t)ts.R : 256u;
+	const uint32_t rpb1 = is_ts ? bthreads * (uint32_t)ts.R : 256u;
 	const dim3 grid_px((unsigned)((n_rays + rpb1 - 1) / rpb1));
 	const dim3 grid_pt((unsigned)((n_rays + rays_per_block - 1) / rays_per_block * chunks));
 	// path-history / accumulator work buffer of the two-stage kernels: 5 x int2 + 3 x float per (padded) path and chunk
@@ -354,8 +386,6 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		acc = (float*)((char*)c->work.p + (size_t)n_work * 40);
 	}
 	sp::ScanSrc src2{};
-	// the record stream the variant reads, derived from the scene on first use
-	if (is_ts && ts.scan == 3 && (rc = ensure_cylm(c, st))) return rc;
 	if (is_ts && (ts.scan == 1 || ts.scan == 2) && (rc = ensure_cyl(c, st))) return rc;
 #ifdef SP_ALL_VARIANTS
 	if (is_ts && ts.scan == 0 && (rc = ensure_filt(c, st))) return rc;
@@ -365,6 +395,7 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	src2.cyl.hdr = (const uint32_t*)c->cyl_hdr.p;
 	src2.cylm.rec = (const float4*)c->cylm_rec.p;
 	src2.cylm.hdr = (const uint32_t*)c->cylm_hdr.p;
+	src2.cylm.big = (const float4*)c->cylm_big.p;
 	const unsigned int* bnd = (const unsigned int*)c->bounds.p;
 	sp::BvhArgs B{};
 	if (variant == kVariantAccel) {
@@ -382,8 +413,9 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		sp::KArgs h = a;
 		h.n_chunks = 0; h.samp = nullptr;
 		const int* no_src = nullptr;
-#define SP_PRIM(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, h, src2, bnd, no_src, oi, od)
+#define SP_PRIM(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block_ts, 0, st, h, src2, bnd, no_src, oi, od)
 		if (ts.scan == 3) SP_PRIM(1, 3);
+		else if (ts.scan == 4) SP_PRIM(1, 4);
 		else if (ts.scan == 2) SP_PRIM(4, 2);
 #ifdef SP_ALL_VARIANTS
 		else if (ts.scan == 0) { if (ts.R == 4) SP_PRIM(4, 0); else if (ts.R == 2) SP_PRIM(2, 0); else SP_PRIM(1, 0); }
@@ -400,8 +432,9 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 	} else if (mode == kModeHits) {
 		int* oi = (int*)d_rgba; float* od = (float*)d_accum;
 		if (is_ts) {
-#define SP_HIT(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd, d_src, oi, od)
+#define SP_HIT(R_, S_) hipLaunchKernelGGL((sp::k_hit_filter<R_, S_>), grid_px, block_ts, 0, st, a, src2, bnd, d_src, oi, od)
 			if (ts.scan == 3) SP_HIT(1, 3);
+			else if (ts.scan == 4) SP_HIT(1, 4);
 			else if (ts.scan == 2) SP_HIT(4, 2);
 #ifdef SP_ALL_VARIANTS
 			else if (ts.scan == 0) { if (ts.R == 4) SP_HIT(4, 0); else if (ts.R == 2) SP_HIT(2, 0); else SP_HIT(1, 0); }
@@ -413,8 +446,9 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		else                   hipLaunchKernelGGL(sp::k_hit<1>, grid, block, 0, st, a, d_src, oi, od);
 	} else if (mode == SPHIP_MODE_FLAT) {
 		if (is_ts) {
-#define SP_FLAT(R_, S_) hipLaunchKernelGGL((sp::k_flat_filter<R_, S_>), grid_px, block, 0, st, a, src2, bnd)
+#define SP_FLAT(R_, S_) hipLaunchKernelGGL((sp::k_flat_filter<R_, S_>), grid_px, block_ts, 0, st, a, src2, bnd)
 			if (ts.scan == 3) SP_FLAT(1, 3);
+			else if (ts.scan == 4) SP_FLAT(1, 4);
 			else if (ts.scan == 2) SP_FLAT(4, 2);
 #ifdef SP_ALL_VARIANTS
 			else if (ts.scan == 0) { if (ts.R == 4) SP_FLAT(4, 0); else if (ts.R == 2) SP_FLAT(2, 0); else SP_FLAT(1, 0); }
@@ -426,8 +460,9 @@ int launch_render(sphip_ctx* c, const void* d_rays, size_t n_rays, const sphip_s
 		else                   hipLaunchKernelGGL(sp::k_flat<1>, grid, block, 0, st, a);
 	} else {
 		if (is_ts) {
-#define SP_PT(R_, SPLIT_, S_) hipLaunchKernelGGL((sp::k_pt_filter<R_, SPLIT_, S_>), grid_pt, block, 0, st, a, src2, bnd, hist, acc, n_work)
+#define SP_PT(R_, SPLIT_, S_) hipLaunchKernelGGL((sp::k_pt_filter<R_, SPLIT_, S_>), grid_pt, block_ts, 0, st, a, src2, bnd, hist, acc, n_work)
 			if (ts.scan == 3) SP_PT(1, false, 3);
+			else if (ts.scan == 4) SP_PT(1, false, 4);
 			else if (ts.scan == 2 && ts.split) SP_PT(4, true, 2);
 #ifdef SP_ALL_VARIANTS
 			else if (ts.scan == 2) SP_PT(4, false, 2);
@@ -886,7 +921,7 @@ void sphip_destroy(sphip_t* c) {
 	(void)hipSetDevice(c->device);
 	if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
 	DevBuf* bufs[] = { &c->tris, &c->mats, &c->scan, &c->filt, &c->bounds, &c->samp, &c->rays, &c->rgba, &c->accum, &c->counter, &c->work,
-	                   &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->sort_kv, &c->sort_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim, &c->cylm_rec, &c->cylm_hdr };
+	                   &c->bvh_nodes, &c->bvh_rec, &c->bvh_idx, &c->sort_kv, &c->sort_hist, &c->bvh_meta, &c->cyl_rec, &c->cyl_cnt, &c->cyl_hdr, &c->prim, &c->cylm_rec, &c->cylm_hdr, &c->cylm_big };
 	for (auto b : bufs) if (b->p) (void)hipFree(b->p);
 	hipEvent_t evs[6] = { c->ev_k0, c->ev_k1, c->ev_u0, c->ev_u1, c->ev_d0, c->ev_d1 };
 	for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -1010,7 +1045,7 @@ int sphip_selftest_device(sphip_t* c, int what, const void* in, size_t n, void* 
 	hipError_t e = hipMalloc(&d_out, n * out_b[what]);
 	if (e == hipSuccess) e = hipMemcpy(d_in, in, n * in_b[what], hipMemcpyHostToDevice);
 	if (e == hipSuccess) {
-		if (what == 6) hipLaunchKernelGGL(sp::k_selftest_cylm, dim3((unsigned)n), dim3(64), 0, k->own_stream, (const float*)d_in, (uint32_t)n, (float*)d_out);
+		if (what == 6) hipLaunchKernelGGL(sp::cylm256::k_selftest_cylm, dim3((unsigned)n), dim3(64), 0, k->own_stream, (const float*)d_in, (uint32_t)n, (float*)d_out);
 		else hipLaunchKernelGGL(sp::k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k->own_stream, what, (const void*)d_in, (uint32_t)n, d_out);
 		e = hipGetLastError();
 	}
@@ -1035,25 +1070,31 @@ int sphip_selftest_stage1(sphip_t* c, const float* rays, size_t n_rays, uint32_t
 	HIP_TRY(c, hipMemcpyAsync(hdr, c->cylm_hdr.p, sizeof hdr, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
 	const uint32_t tiles = hdr[6];
-	*tiles_out = tiles;
+	const uint32_t T = c->cylm_wide ? sp::cylm512::kMTile : sp::cylm256::kMTile, W = c->cylm_wide ? sp::cylm512::kMWords : sp::cylm256::kMWords;
+	*tiles_out = tiles | (T << 20);                        // tiles of the stream (low 20 bits) and triangles per tile
 	if (!out_words) return SPHIP_OK;
 	if (!rays || !out_order || n_rays == 0 || n_rays % 64 || n_rays > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad stage-1 selftest arguments (n_rays=%zu)", n_rays);
-	const size_t words_b = n_rays * tiles * 2 * sizeof(uint32_t), order_b = (size_t)tiles * sp::kMTile * sizeof(int32_t);
+	const size_t words_b = n_rays * tiles * 2 * W * sizeof(uint32_t), tri_b = n_rays * tiles * 2 * (T / 64) * sizeof(uint32_t),
+	             order_b = (size_t)tiles * T * sizeof(int32_t);
 	void *d_rays = nullptr, *d_words = nullptr, *d_order = nullptr, *d_tri = nullptr;
 	hipError_t e = hipMalloc(&d_rays, n_rays * 24);
 	if (e == hipSuccess) e = hipMalloc(&d_words, words_b);
-	if (e == hipSuccess && out_tri) e = hipMalloc(&d_tri, words_b * 4);
+	if (e == hipSuccess && out_tri) e = hipMalloc(&d_tri, tri_b);
 	if (e == hipSuccess) e = hipMalloc(&d_order, order_b);
 	if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n_rays * 24, hipMemcpyHostToDevice, st);
 	if (e == hipSuccess) {
-		sp::CylStream cs{ (const float4*)c->cylm_rec.p, (const uint32_t*)c->cylm_hdr.p };
-		hipLaunchKernelGGL(sp::k_selftest_stage1, dim3((unsigned)(n_rays / 64)), dim3(64), 0, st, (const float*)d_rays, (uint32_t)n_rays, cs,
+		sp::CylStream cs{ (const float4*)c->cylm_rec.p, (const uint32_t*)c->cylm_hdr.p, (const float4*)c->cylm_big.p };
+		if (c->cylm_wide)
+			hipLaunchKernelGGL(sp::cylm512::k_selftest_stage1, dim3((unsigned)(n_rays / 64)), dim3(64), 0, st, (const float*)d_rays, (uint32_t)n_rays, cs,
+		                   (const unsigned int*)c->bounds.p, (uint32_t*)d_words, (uint32_t*)d_tri, (int*)d_order);
+		else
+			hipLaunchKernelGGL(sp::cylm256::k_selftest_stage1, dim3((unsigned)(n_rays / 64)), dim3(64), 0, st, (const float*)d_rays, (uint32_t)n_rays, cs,
 		                   (const unsigned int*)c->bounds.p, (uint32_t*)d_words, (uint32_t*)d_tri, (int*)d_order);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(out_words, d_words, words_b, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipMemcpyAsync(out_order, d_order, order_b, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess && out_tri) e = hipMemcpyAsync(out_tri, d_tri, words_b * 4, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && out_tri) e = hipMemcpyAsync(out_tri, d_tri, tri_b, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
 	if (d_rays) (void)hipFree(d_rays);
 	if (d_words) (void)hipFree(d_words);

@@ -26,7 +26,7 @@ def test_bench_line_small_workload():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["unit"] == "Mray/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["unit"] == "Mray/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"].startswith("f32")
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     # the binding roof is FP32 vector issue: peak 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; the fraction needs a committed PMC pass for
