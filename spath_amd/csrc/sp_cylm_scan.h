@@ -664,15 +664,19 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				}
 				SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_retest, ph_t0, ph_t1);
 				// ---- (b): the candidates go on the wave's stack; a full batch of 64 is tested as soon as the next ones would not fit
-#pragma unroll 1
-				for (int u = 0; u < 4; ++u) {                                // (not unrolled: one copy of the batch code)
-					const bool mine = (cand >> u) & 1u;
+				// one pass per candidate RANK, not per place in the group: a lane's first candidate, then its second, ... (1.04 candidates
+				// per entry: the second pass is short and the third and fourth hardly ever run)
+				for (;;) {
+					const bool mine = cand != 0u;
 					const unsigned long long mk = __ballot(mine);
+					if (mk == 0ull) break;
 					const uint32_t cnt = (uint32_t)__popcll(mk);
 					if (q2n + cnt > kMQ2) exact_batch(64u);                  // q2n > kMQ2 - 64 >= 64 here
-					const uint32_t idx = u == 0 ? idx4[0] : u == 1 ? idx4[1] : u == 2 ? idx4[2] : idx4[3];
+					const uint32_t low = cand & (0u - cand);
+					const uint32_t idx = (low & 1u) ? idx4[0] : (low & 2u) ? idx4[1] : (low & 4u) ? idx4[2] : idx4[3];
 					if (mine) myq2[q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = ((uint32_t)L << kMIdxBits) | idx;
 					q2n += cnt;
+					cand ^= low;
 				}
 				__builtin_amdgcn_wave_barrier();
 				SP_PH_STAMP(ph_t0); SP_PH_ADD(ph_exact, ph_t1, ph_t0);

@@ -1,6 +1,7 @@
 """Randomized soak of the two-stage scans against the exact-only scan (bit for bit): python tools/soak.py [seconds] [seed]
 Random scenes (closed room, open clutter, raw triangle soups over several decades of size with slivers, duplicated and degenerate
-triangles; triangle counts around the 64 / 256 / 384-triangle boundaries), random image sizes, spp, seeds, shards and chunk counts.
+triangles; triangle counts around the 64 / 256 / 384 / 512-triangle boundaries), random image sizes, spp, seeds, shards and chunk
+counts; every third scene forces the other workgroup shape of the default scan (SPATH_HIP_CYLM_SHAPE).
 Checks path-traced accumulators + RGBA8 + scan counts, the flat pass, and the scan alone with random idx_source."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +11,7 @@ from spath_amd import capi, scene, view
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 ctx = capi.Context(0)
-TWO = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16]
+TWO = [v for v in capi.available_variants() if v >= 3 and v != 8]        # shipped build: 15, 16; -DSP_ALL_VARIANTS: every generation
 names = {v: k for k, v in capi.kernel_variants().items()}
 
 
@@ -35,7 +36,10 @@ def soup(n):
 t_end, it, fails = time.time() + budget, 0, 0
 while time.time() < t_end:
     it += 1
-    n = int(rng.choice([rng.integers(1, 70), rng.integers(250, 262), rng.integers(378, 392), rng.integers(760, 776), rng.integers(64, 4000), rng.integers(4000, 30000)]))
+    n = int(rng.choice([rng.integers(1, 70), rng.integers(250, 262), rng.integers(378, 392), rng.integers(506, 520), rng.integers(760, 776), rng.integers(1020, 1030),
+                        rng.integers(64, 4000), rng.integers(4000, 30000), rng.integers(30000, 60000)]))
+    if it % 3 == 0: os.environ["SPATH_HIP_CYLM_SHAPE"] = str(rng.choice([256, 512]))
+    else: os.environ.pop("SPATH_HIP_CYLM_SHAPE", None)
     kind = rng.integers(0, 3)
     if kind == 0 and n >= 14: t, m = scene.closed_room(n, seed=int(rng.integers(1, 1 << 30)), clutter_scale=float(rng.choice([1.0, 1.0, 3.0, 10.0])))
     elif kind == 1 and n >= 7: t, m = scene.open_clutter(n, seed=int(rng.integers(1, 1 << 30)))
