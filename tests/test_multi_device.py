@@ -107,6 +107,20 @@ def test_multi_device_full_frame_and_rccl_communicator(hip):
            "print('rccl-one', bool(np.array_equal(got, want)), st['gather_kind'], c.device_count, c.description)\n")
     p = subprocess.run([os.sys.executable, "-c", one], capture_output=True, text=True, env=env, cwd=ROOT)
     assert "rccl-one True 1 1" in p.stdout and "RCCL gather" in p.stdout, p.stdout + p.stderr[-2000:]
+    # the same communicator of one on the frame shapes that leave ranks without tiles on a real node ((16, 5): two tiles for eight
+    # devices), a single row, a single pixel, the flat pass, the camera path and accumulators: the RCCL branch of multi_render
+    # (group start / end with nothing to send, local copy of the root's own tiles, assemble, D2H) as far as one device reaches
+    shapes = ("import numpy as np\nfrom spath_amd import capi, scene, view\n"
+              "t, m = scene.closed_room(300)\na = capi.Context(0); a.set_scene(t, m)\nc = capi.Context.multi([0]); c.set_scene(t, m)\nok = True\n"
+              "for (w, h, spp) in [(16, 5, 3), (97, 1, 2), (1, 1, 4), (33, 20, 1)]:\n"
+              "    cam = view.Camera(w, h); rays = cam.get_viewport()\n"
+              "    wi, wa = a.render(rays, w, h, spp, seed=9, want_accum=True); gi, ga = c.render(rays, w, h, spp, seed=9, want_accum=True)\n"
+              "    ok &= bool(np.array_equal(wi, gi) and np.array_equal(wa, ga)) and c.stats()['gather_kind'] == 1 and c.stats()['scans_executed'] == a.stats()['scans_executed']\n"
+              "    ok &= bool(np.array_equal(a.render(rays, w, h, 1, mode=capi.MODE_FLAT), c.render(rays, w, h, 1, mode=capi.MODE_FLAT)))\n"
+              "    ok &= bool(np.array_equal(c.render_camera(cam, spp, seed=9), wi))\n"
+              "print('rccl-shapes', ok)\n")
+    p = subprocess.run([os.sys.executable, "-c", shapes], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert "rccl-shapes True" in p.stdout, p.stdout + p.stderr[-2000:]
     p = subprocess.run([os.sys.executable, "-c",
                         "from spath_amd import capi\n"
                         "import ctypes as C\n"
