@@ -173,15 +173,9 @@ def test_stage1_never_rejects_a_pair_the_reference_accepts(hip, O):
 
 def _unpinned_lib():
     """The default library with the one-conversion-per-value guard of sp_cylm_scan.h (to_half) compiled out."""
-    out = os.path.join(ROOT, "build", "libspath_hip_unpinned.so")
-    csrc = os.path.join(ROOT, "spath_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
-    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
-        sys.path.insert(0, ROOT)
-        import __graft_entry__ as g
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(g.hipcc_command(out, ["-DSP_CYLM_UNPINNED"]), cwd=ROOT)
-    return out
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    return g.build_unpinned()
 
 
 def test_audit_fails_on_the_build_with_the_conversion_defect():
