@@ -44,6 +44,11 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (~2.5 PF)
 VALU_MEASURED_FMAC_TINSTR = 56.7   # measured on MI355X, 4 waves/SIMD, independent v_fmac_f32 chains (profiles/r01_valu_microbench_extended.log)
 VALU_PEAK_TINSTR = 256 * 4 * 32 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.64 T lane-instructions/s
+# Only f32 add / mul / fma issue at that rate.  Measured at the kernel's 4 waves per SIMD (tools/valu_bench2.hip, profiles/r03_valu_microbench_classes.log):
+# v_fma_f32 55.2, v_sub_f32 57.7, v_fmac_f32 53.7 T lane-instr/s -- and 34.4 - 35.8 for v_minimum3_f32, v_min3_f32, v_min_f32, v_max_f32, v_alignbit_b32,
+# v_lshl_or_b32: 16 lanes/clk, 4 cycles per wave64 instruction.  The mix of the kernel comes from the per-type SQ counters (valu_issue.json "classes").
+VALU_CLASS_CYCLES = {"full": 2.0, "half": 4.0, "trans": 8.0}             # nominal issue cycles per wave64 instruction
+VALU_CLASS_MEASURED_TINSTR = {"full": 55.2, "half": 34.5, "trans": 18.2}  # sustained at 4 waves/SIMD (trans: v_rcp_f32, profiles/r01_valu_microbench_extended.log)
 BYTES_PER_TEST = 48          # sizeof(geom::triangle)
 FLOPS_PER_TEST = 52
 
@@ -413,6 +418,25 @@ def main():
         tests_per_s = my_scans * NT / avg_kernel_s
         lane_instr = vi.get("lane_instr_per_test")
         valu_achieved = tests_per_s * lane_instr / 1e12 if lane_instr else None
+        # the same instructions priced by issue class (see VALU_CLASS_*): what share of the SIMDs' issue time the kernel's own mix needs
+        issue_classes = None
+        cls = vi.get("classes") if vi else None
+        if cls and valu_achieved and cls.get("source_hash") == lib_hash:
+            mix = {"full": cls["full_rate_frac"], "half": cls["half_rate_frac"], "trans": cls["trans_frac"]}
+            cyc = sum(mix[k] * VALU_CLASS_CYCLES[k] for k in mix)                         # nominal issue cycles per wave64 instruction of this mix
+            sec_per_tinstr = sum(mix[k] / VALU_CLASS_MEASURED_TINSTR[k] for k in mix)     # seconds per 1e12 lane-instructions at the measured class rates
+            issue_classes = {
+                "full_rate_frac": mix["full"], "half_rate_frac": mix["half"], "trans_frac": mix["trans"],
+                "nominal_cycles_per_instr": round(cyc, 3),
+                "frac_class_weighted": round(valu_achieved / (VALU_PEAK_TINSTR * 2.0 / cyc), 4),
+                "frac_of_measured_class_rates": round(valu_achieved * sec_per_tinstr, 4),
+                "note": "only f32 add/mul/fma issue at the 32 lanes/clk of `peak`; min/max, integer, compare/select, bit and cross-lane instructions issue at 16 "
+                        "(measured: profiles/r03_valu_microbench_classes.log).  frac_class_weighted prices every instruction at its nominal issue cycles (2 / 4 / 8); "
+                        "frac_of_measured_class_rates at the rates a pure stream of each class sustains at this kernel's 4 waves per SIMD",
+                "source": cls.get("source"),
+            }
+        elif cls:
+            issue_classes = {"note": "class mix measured on another build of the library: not applied", "measured_on": cls.get("source_hash")}
         out = {
             "metric": "Mray/s (primary x spp x bounces)",
             "value": round(value, 3),
@@ -464,6 +488,7 @@ def main():
                 "peak_definition": "256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md); one wave64 VALU instruction = 2 issue cycles",
                 # what a pure stream of independent v_fmac_f32 issues on this chip at the kernel's 4 waves per SIMD (tools/valu_bench.hip,
                 # profiles/r01_valu_microbench_extended.log: 56.7 T lane-instr/s; v_fma_f32 50-55, three-source min/med ops 31.5)
+                "issue_classes": issue_classes,
                 "measured_fmac_issue_rate": VALU_MEASURED_FMAC_TINSTR,
                 "frac_of_measured_fmac_rate": round(valu_achieved / VALU_MEASURED_FMAC_TINSTR, 4) if valu_achieved else None,
                 "sclk_observed_mhz": round(sclk_mhz, 1) if sclk_mhz else None,

@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt -o p --output-format csv -- $B 
 P="--steps 1 --warmup 0 --no-cpu-baseline --no-worst-case"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/${TAG}_pmc_sq -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_sq.json 2> $O/${TAG}_pmc_sq.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $O/${TAG}_pmc_wait -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_wait.json 2> $O/${TAG}_pmc_wait.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE -d $O/${TAG}_pmc_cls -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_cls.json 2> $O/${TAG}_pmc_cls.err
 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_fetch.json 2> $O/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_write.json 2> $O/${TAG}_pmc_write.err
 python3 tools/render_once.py rpl_cylm 1920 1080 16 10000 build/libspath_hip_stats.so > $O/${TAG}_filter_stats.log 2>&1 || true

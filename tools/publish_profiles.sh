@@ -19,6 +19,11 @@ cp $O/${TAG}_pmc_write/p_counter_collection.csv profiles/${R}_bench_pmc_WRITE_SI
 grep -v "amdgpu.ids" $O/${TAG}_filter_stats.log > profiles/${R}_filter_stats_build.log
 HASH=$(python3 -c "import json,sys; print(json.loads([l for l in open('$O/${TAG}_bench_pmc_sq.json') if l.startswith('{')][-1])['library_source_hash'])")
 python3 tools/valu_issue_from_pmc.py profiles/${R}_bench_pmc_sq_counters.csv profiles/${R}_bench_pmc_sq_run.json $RND
+if [ -f $O/${TAG}_pmc_cls/p_counter_collection.csv ]; then
+  cp $O/${TAG}_pmc_cls/p_counter_collection.csv profiles/${R}_bench_pmc_valu_classes.csv
+  cp $O/${TAG}_bench_pmc_cls.json profiles/${R}_bench_pmc_valu_classes_run.json
+  python3 tools/valu_classes_from_pmc.py profiles/${R}_bench_pmc_valu_classes.csv profiles/${R}_bench_pmc_valu_classes_run.json $RND
+fi
 python3 tools/hbm_traffic_from_pmc.py profiles/${R}_bench_pmc_FETCH_SIZE.csv profiles/${R}_bench_pmc_WRITE_SIZE.csv 10000tris_1920x1080x256_g1_${KERNEL} $RND $HASH
 python3 tools/filter_stats_from_log.py profiles/${R}_filter_stats_build.log 10000 1920 1080 ${KERNEL} "statistics build (-DSP_FILTER_STATS) of the same kernel, configs[2] frame at 16 spp (profiles/${R}_filter_stats_build.log)"
 for S in config3 config4; do
