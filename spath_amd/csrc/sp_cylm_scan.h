@@ -620,6 +620,22 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			if (all == 0u) break;
 			uint32_t j = incl - c;
 			const uint32_t jend = incl < kMCap ? incl : kMCap;            // what does not fit stays in the words for the next pass
+			if (all <= kMCap) {
+				// everything fits (nearly always): no capacity test per entry, and a plain per-lane loop -- six vector instructions per entry
+#pragma unroll
+				for (int w = 0; w < (int)kMWords; ++w)
+#pragma unroll
+				for (int rb = 0; rb < 2; ++rb) {
+					uint32_t m = word[w][rb];
+					const uint32_t eb = (((lane & 31u) + 32u * (uint32_t)rb) << 7) | (64u * (uint32_t)w + hh);
+					while (m != 0u) {
+						const uint32_t e = (uint32_t)__builtin_clz(m);
+						mylst[j++] = (unsigned short)(eb + 2u * e);       // (indexed: behind a walking pointer hipcc no longer knows the list from the tile an LDS-DMA is filling)
+						m &= ~(0x80000000u >> e);
+					}
+					word[w][rb] = 0u;
+				}
+			} else
 #pragma unroll
 			for (int w = 0; w < (int)kMWords; ++w)
 #pragma unroll
