@@ -467,9 +467,13 @@ SP_DEV void cylm_stage1(const float4* cur, uint32_t tb0, uint32_t nblk, uint32_t
 	word[1] = cylm_bits(g1, Hm, R.Dn[1], R.Dqn[1], word[1]);
 }
 
-constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: ray << 7 | group); what does not fit waits for the next pass
+constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: group << 8 | ray << 2); what does not fit waits for the next pass
 constexpr uint32_t kMQ2 = 128u;              // exact-test candidates a wave can hold (32 bits each: ray << 26 | triangle index)
 constexpr uint32_t kMIdxBits = 26u;          // hence at most 2^26 - 1 triangles for this scan (the host picks another one beyond)
+
+// value of lane (addr4 / 4) of the wave: ds_bpermute_b32 on a byte address the caller already holds (__shfl would rebuild it: and, or, shift)
+SP_DEV float wave_fetch(uint32_t addr4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)addr4, __float_as_int(v))); }
+SP_DEV int wave_fetch(uint32_t addr4, int v) { return __builtin_amdgcn_ds_bpermute((int)addr4, v); }
 
 // inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then the row
 // totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six v_add_u32_dpp, no LDS.  Full waves only.
@@ -541,16 +545,18 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		const bool ok = lane < n;
 		// idle lanes (only in the last batch of a scan): their own ray against the zero record behind the last triangle
 		const uint32_t e = ok ? myq2[q2n - n + lane] : ((lane << kMIdxBits) | a.n_tris);
-		const int L = (int)(e >> kMIdxBits);
+		const uint32_t la = (e >> (kMIdxBits - 2u)) & 0xfcu;                             // 4 x donor lane: the ds_bpermute address
 		const int idx = (int)(e & ((1u << kMIdxBits) - 1u));
-		const float4 x0 = a.scan[3 * (size_t)idx + 0], x1 = a.scan[3 * (size_t)idx + 1], x2 = a.scan[3 * (size_t)idx + 2];
-		const float ox = __shfl(s.o[0].x, L, 64), oy = __shfl(s.o[0].y, L, 64), oz = __shfl(s.o[0].z, L, 64);
-		const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
-		const int src = __shfl(s.src[0], L, 64);
+		// 48 idx by shift and add (v_mul_lo_u32 is a quarter-rate instruction); idx < 2^26: the byte offset fits 32 bits
+		const float4* const rec = (const float4*)((const char*)a.scan + ((((uint32_t)idx << 1) + (uint32_t)idx) << 4));
+		const float4 x0 = rec[0], x1 = rec[1], x2 = rec[2];
+		const float ox = wave_fetch(la, s.o[0].x), oy = wave_fetch(la, s.o[0].y), oz = wave_fetch(la, s.o[0].z);
+		const float dx = wave_fetch(la, s.dir[0].x), dy = wave_fetch(la, s.dir[0].y), dz = wave_fetch(la, s.dir[0].z);
+		const int src = wave_fetch(la, s.src[0]);
 		const float d = ray_tri_strict(mk3(ox, oy, oz), mk3(dx, dy, dz), mk3(x0.x, x0.y, x0.z), mk3(x0.w, x1.x, x1.y), mk3(x1.z, x1.w, x2.x));
 		// cpu_renderer.cpp:44: cur_d > 0 && cur_d < d, d starting at MAX_VALUE_DIST; ties -> lowest index: the key's low word
 		if (ok && (d > 0.0f) && (d < kMaxDist) && (idx != src))
-			atomicMin(&cell[(int)wbase + L], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)idx);
+			atomicMin(&cell[wbase + (la >> 2)], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)idx);
 		q2n -= n;
 #ifdef SP_FILTER_STATS
 		if (lane == 0) { atomicAdd(a.scans + 5, 1ull); atomicAdd(a.scans + 4, (unsigned long long)n); }
@@ -605,7 +611,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 #ifdef SP_CYLM_LATE_DMA
 		if (gt + 1u < total_tiles) cylm_tile_dma(cs.rec + (size_t)(gt + 1u) * kMTileQ, nxt, tid, wbase);
 #endif
-		// ---- stage 2 (a): one list per wave; entry = (ray = donor lane) << 6 | group
+		// ---- stage 2 (a): one list per wave; entry = group << 8 | (ray = donor lane) << 2
 #ifdef SP_EXP_NO_STAGE2
 		for (int w = 0; w < (int)kMWords; ++w) exp_acc ^= word[w][0] ^ word[w][1];
 		for (; false;) {
@@ -621,16 +627,16 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			uint32_t j = incl - c;
 			const uint32_t jend = incl < kMCap ? incl : kMCap;            // what does not fit stays in the words for the next pass
 			if (all <= kMCap) {
-				// everything fits (nearly always): no capacity test per entry, and a plain per-lane loop -- six vector instructions per entry
+				// everything fits (nearly always): no capacity test per entry, and a plain per-lane loop -- seven vector instructions per entry
 #pragma unroll
 				for (int w = 0; w < (int)kMWords; ++w)
 #pragma unroll
 				for (int rb = 0; rb < 2; ++rb) {
 					uint32_t m = word[w][rb];
-					const uint32_t eb = (((lane & 31u) + 32u * (uint32_t)rb) << 7) | (64u * (uint32_t)w + hh);
+					const uint32_t eb = (((lane & 31u) + 32u * (uint32_t)rb) << 2) | ((64u * (uint32_t)w + hh) << 8);
 					while (m != 0u) {
 						const uint32_t e = (uint32_t)__builtin_clz(m);
-						mylst[j++] = (unsigned short)(eb + 2u * e);       // (indexed: behind a walking pointer hipcc no longer knows the list from the tile an LDS-DMA is filling)
+						mylst[j++] = (unsigned short)(eb + (e << 9));       // (indexed: behind a walking pointer hipcc no longer knows the list from the tile an LDS-DMA is filling)
 						m &= ~(0x80000000u >> e);
 					}
 					word[w][rb] = 0u;
@@ -645,7 +651,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				while (__any(m != 0u && j < jend)) {
 					if (m != 0u && j < jend) {
 						const uint32_t e = (uint32_t)__builtin_clz(m);                      // e-th appended bit of word w: fragment 8 w + e / 4, j = e % 4
-						mylst[j++] = (unsigned short)((ray << 7) | (64u * (uint32_t)w + 2u * e + hh));     // group 8 tb + 2 j + hh = 64 w + 2 e + hh
+						mylst[j++] = (unsigned short)((ray << 2) | ((64u * (uint32_t)w + 2u * e + hh) << 8));     // group 8 tb + 2 j + hh = 64 w + 2 e + hh
 						m &= ~(0x80000000u >> e);
 					}
 				}
@@ -660,39 +666,45 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			for (uint32_t base = 0; base < total; base += 64u) {
 				const uint32_t ent = base + lane;
 				const bool ok = ent < total;
-				const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 7);
-				const int L = (int)(entry >> 7);
-				const uint32_t grp = entry & 127u;
-				const float dx = __shfl(s.dir[0].x, L, 64), dy = __shfl(s.dir[0].y, L, 64), dz = __shfl(s.dir[0].z, L, 64);
-				const float Pa = __shfl(f.Pa[0], L, 64), Pb = __shfl(f.Pb[0], L, 64), Pc = __shfl(f.Pc[0], L, 64);
-				const float D = __shfl(f.D[0], L, 64), Dq = __shfl(f.Dq[0], L, 64);
-				// the f32 cylinder test of sp_cyl_scan.h on the group's four records, each with its own H: which of them survive
+				// entry = group << 8 | 4 ray: the low byte is the ds_bpermute address of the donor lane as it stands
+				const uint32_t entry = ok ? (uint32_t)mylst[ent] : (lane << 2);
+				const uint32_t la = entry & 0xfcu;
+				const uint32_t grp = entry >> 8;
+				const float dx = wave_fetch(la, s.dir[0].x), dy = wave_fetch(la, s.dir[0].y), dz = wave_fetch(la, s.dir[0].z);
+				const float Pa = wave_fetch(la, f.Pa[0]), Pb = wave_fetch(la, f.Pb[0]), Pc = wave_fetch(la, f.Pc[0]);
+				const float D = wave_fetch(la, f.D[0]), Dq = wave_fetch(la, f.Dq[0]);
+				// the f32 cylinder test of sp_cyl_scan.h on the group's four records, each with its own H: which of them survive.  The SIGN of
+				// x - Dq, shifted in as in stage 1 (bit 3 - u = triangle u): one half-rate instruction per triangle instead of compare, mask,
+				// select and or.  (survive <=> !(x - Dq >= 0); where the difference is a NaN -- inf - inf: padding records under a ray whose
+				// filter is off, or an idle lane -- either answer is right.)
 				uint32_t cand = 0;
 				const CylmGroup G = cylm_group(cur, grp);
-				const float4 gi = cur[cylm_slot(grp, 6u)];
-				const uint32_t idx4[4] = { __float_as_uint(gi.x), __float_as_uint(gi.y), __float_as_uint(gi.z), __float_as_uint(gi.w) };
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
 					const float mz = u == 0 ? G.mh01.x : u == 1 ? G.mh01.z : u == 2 ? G.mh23.x : G.mh23.z;
 					const float Hh = u == 0 ? G.mh01.y : u == 1 ? G.mh01.w : u == 2 ? G.mh23.y : G.mh23.w;
 					const float x = cyl_x(G.q0[u], mz, Hh, Pa, Pb, Pc, -dx, -dy, -dz, D);
-					cand |= (ok && !(x - Dq >= 0.0f)) ? (1u << u) : 0u;
+					cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(x - Dq), 31);
 				}
+				cand = ok ? cand : 0u;
 				SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_retest, ph_t0, ph_t1);
 				// ---- (b): the candidates go on the wave's stack; a full batch of 64 is tested as soon as the next ones would not fit
 				// one pass per candidate RANK, not per place in the group: a lane's first candidate, then its second, ... (1.04 candidates
-				// per entry: the second pass is short and the third and fourth hardly ever run)
+				// per entry: the second pass is short and the third and fourth hardly ever run).  The triangle index is read from the
+				// record (one 4-byte LDS read) when its place is known, instead of all four read and selected.
+				const uint32_t* const gidx = (const uint32_t*)(cur + cylm_slot(grp, 6u));
+				const uint32_t lhi = la << (kMIdxBits - 2u);                       // ray << kMIdxBits
 				for (;;) {
 					const bool mine = cand != 0u;
 					const unsigned long long mk = __ballot(mine);
 					if (mk == 0ull) break;
 					const uint32_t cnt = (uint32_t)__popcll(mk);
 					if (q2n + cnt > kMQ2) exact_batch(64u);                  // q2n > kMQ2 - 64 >= 64 here
-					const uint32_t low = cand & (0u - cand);
-					const uint32_t idx = (low & 1u) ? idx4[0] : (low & 2u) ? idx4[1] : (low & 4u) ? idx4[2] : idx4[3];
-					if (mine) myq2[q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = ((uint32_t)L << kMIdxBits) | idx;
+					const uint32_t k = mine ? (uint32_t)__builtin_ctz(cand) : 3u;    // bit k = triangle 3 - k
+					const uint32_t idx = gidx[3u - k];
+					if (mine) myq2[q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = lhi | idx;
 					q2n += cnt;
-					cand ^= low;
+					cand &= cand - 1u;
 				}
 				__builtin_amdgcn_wave_barrier();
 				SP_PH_STAMP(ph_t0); SP_PH_ADD(ph_exact, ph_t1, ph_t0);
