@@ -1,5 +1,5 @@
 """First contact of a new scan build: every build/abl_*.so renders the configs[2] frame at a few spp (timing, SHA-256 of RGBA8 and
-accumulators: all builds must agree with the exact-only scan of the first one) + the large scenes of tools/ab_big.py.
+accumulators: all builds must agree with the exact-only scan of the first one) + the large scenes (clutter x 10, 100k, 1M triangles).
 python tools/first_contact.py [spp]"""
 import glob, hashlib, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

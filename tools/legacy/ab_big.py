@@ -1,6 +1,6 @@
 """A/B of alternative builds (build/abl_*.so): worst-case scene (clutter x10) and the 100k-triangle 4K slice: python tools/ab_big.py"""
 import glob, os, subprocess, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = """
 import os, sys
 sys.path.insert(0, %r)

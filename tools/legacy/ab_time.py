@@ -1,6 +1,6 @@
 """A/B timing of alternative builds (build/abl_*.so) on the configs[2] frame: python tools/ab_time.py [spp] [variants...]"""
 import glob, os, subprocess, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 spp = sys.argv[1] if len(sys.argv) > 1 else "32"
 variants = sys.argv[2:] or ["rpl_cyl2s", "rpl_cyl4s"]
 for lib in sorted(glob.glob(os.path.join(root, "build", "abl_*.so"))):

@@ -1,6 +1,6 @@
 """Timing experiments on the standalone closest-hit kernel (fixed number of scans whatever the results)."""
 import os, sys, glob, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) > 1:
     import numpy as np, torch
     from spath_amd import capi
@@ -19,6 +19,6 @@ if len(sys.argv) > 1:
             ctx.closest_hit_device(d_r.data_ptr(), n, d_i.data_ptr(), d_d.data_ptr(), flags=var); st = ctx.stats()
         print(f"{os.path.basename(sys.argv[1]):50s} var={var} {st['kernel_ms']:8.1f} ms  {n*ntri/st['kernel_ms']/1e9:.3f} T tests/s  hits={(d_i>=0).float().mean().item():.3f}", flush=True)
 else:
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     for lib in sorted(glob.glob(os.path.join(root, "build", "abl_*.so"))):
         subprocess.run([sys.executable, __file__, lib])

@@ -1,6 +1,6 @@
 """SURVEY 8(f4) opt-in acceleration structure: nominal Mray/s and agreement with the brute-force scan by scene size."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from spath_amd import capi, scene, view
 ctx = capi.Context(0)

@@ -1,6 +1,6 @@
 """Configs 4 and 5 shapes (100k and 1M triangles) at reduced image size: throughput + exact-vs-filter agreement."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from spath_amd import capi, scene, view
 ctx = capi.Context(0)

@@ -1,6 +1,6 @@
 """Whole configs[2] frame at 256 spp with forced sample-chunk counts (0 = the library's choice)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 ctx = capi.Context(0)

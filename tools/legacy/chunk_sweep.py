@@ -1,6 +1,6 @@
 """Sample-chunk sweep: kernel time of the path-traced launch for forced chunk counts, whole 1080p frame and 1/8 shard."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 from spath_amd.dist import RowTilePlan, ShardedRenderer

@@ -1,6 +1,6 @@
 """Rate of the whole-frame path-traced launch vs samples per pixel and iterations per lane (sample chunks forced)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 from spath_amd.dist import RowTilePlan, ShardedRenderer

@@ -5,7 +5,7 @@ configs[3]: 100k triangles, 3840x2160, 1024 spp, pixel-row tiles over 8 GPUs -> 
 configs[4]: 1M triangles, 3840x2160, 4096 spp -> 64 interleaved rows x 64 spp, rate extrapolated.
 """
 import os, sys, json, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 from spath_amd.dist import RowTilePlan, ShardedRenderer
@@ -34,4 +34,4 @@ def run(tag, ntri, plan, rank, spp, full_spp):
 
 run("configs[3] rank-0 shard of 8 (100k tris, 4K, 1024 spp)", 100000, RowTilePlan(W, H, 8, 8), 0, 1024, 1024)
 run("configs[4] slice (1M tris, 4K, 64 rows x 64 spp of 4096)", 1000000, RowTilePlan(W, H, 34, 8), 0, 64, 4096)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "config45.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "config45.json"), "w"), indent=1)

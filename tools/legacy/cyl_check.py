@@ -1,7 +1,7 @@
 """First contact of the cylinder-filter scan variants (sp_cyl_scan.h) on a GPU: parity against the exact scan and the oracle,
 then timings against the first-generation filter variants.  python tools/cyl_check.py [quick]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 from oracle import oracle as O

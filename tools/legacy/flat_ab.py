@@ -1,6 +1,6 @@
 """A/B of alternative builds (build/abl_*.so) on the flat pass (one scan per pixel, all rays from the camera): python tools/flat_ab.py [w h tris]"""
 import glob, os, subprocess, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 args = sys.argv[1:4] if len(sys.argv) > 3 else ["3840", "2160", "10000"]
 code = """
 import os, sys

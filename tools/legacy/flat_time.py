@@ -1,6 +1,6 @@
 """render_flat (one scan per pixel) timing by kernel variant: python tools/flat_time.py [w h tris]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 w, h, nt = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1920, 1080, 10000)))

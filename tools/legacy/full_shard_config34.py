@@ -4,7 +4,7 @@ run reports progress): RGBA8 and float accumulators must be identical.  Then the
 python tools/full_shard_config34.py [spp3 [spp4 [3|4|34]]]      ONLY_TWO_STAGE=1: skip the exact-only scan (18 minutes at configs[3]) and
 print the two-stage SHA-256 to compare with the exact-only one of an earlier run (same seeds, same pieces: same bytes)."""
 import hashlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from spath_amd import capi, scene, view
 from spath_amd.dist import RowTilePlan

@@ -1,6 +1,6 @@
 """Quick GPU spot check: parity of every kernel variant vs the oracle + timings on the closed-room scene."""
 import os, sys, time, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O
 from spath_amd import capi, scene, view

@@ -1,5 +1,5 @@
 import os, sys, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spath_amd import capi
 capi.LIB_PATH = sys.argv[1]
 from spath_amd import scene, view
