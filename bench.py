@@ -210,6 +210,7 @@ def main():
                     "primary-hit reuse and the opt-in acceleration structure, and report them under reference_runs_untimed; "
                     "off by default so that a profile of the default command contains only the timed kernel")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the (untimed) large-triangle scene figure")
+    ap.add_argument("--no-valu-microbench", action="store_true", help="do not run build/valu_bench2 (the per-class VALU issue rates of THIS box, ~1 s, untimed)")
     ap.add_argument("--cpu-w", type=int, default=192)
     ap.add_argument("--cpu-h", type=int, default=108)
     ap.add_argument("--cpu-spp", type=int, default=32, help="the CPU sample's spp (default: ~30 s of the reference on 16 threads, 0.25 s poll quantum < 1 %)")
@@ -350,6 +351,26 @@ def main():
         torch.cuda.synchronize()
         exact_only["with_accel_structure_opt_in"] = {"spp": spp_r, "kernel_ms": round(e0.elapsed_time(e1), 3),
                                                      "nominal_Mray_per_s": round(W * H * spp_r * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 2)}
+    # the VALU issue rates of this box by instruction class (untimed, a child process, GPU otherwise idle): tools/valu_bench2.hip, built by
+    # __graft_entry__.build() into build/valu_bench2; without it the committed rates of profiles/r03_valu_microbench_classes.log are used
+    live_rates = None
+    vb2 = os.path.join(ROOT, "build", "valu_bench2")
+    if world == 1 and not args.no_valu_microbench and os.path.exists(vb2):
+        try:
+            import subprocess
+            out = subprocess.run([vb2], capture_output=True, text=True, timeout=120).stdout
+            rate = {}
+            for line in out.splitlines():
+                if "waves/SIMD=4" in line:
+                    rate[line.split("waves/SIMD=4")[0].strip()] = float(line.split("waves/SIMD=4")[1].split()[0]) / 1e3    # T lane-instr/s
+            full = [v for k, v in rate.items() if k.startswith(("v_fma_f32", "v_sub_f32", "v_fmac_f32"))]
+            half = [v for k, v in rate.items() if k.startswith(("v_minimum3_f32", "v_alignbit_b32", "v_min_f32", "v_max_f32", "v_min3_f32", "v_lshl_or_b32"))]
+            if full and half:
+                live_rates = {"full": round(sum(full) / len(full), 2), "half": round(sum(half) / len(half), 2),
+                              "stage1_block": round(rate.get("stage-1 block: 2 x (minimum3 x2, fma, sub, alignbit)", 0.0), 2),
+                              "source": "build/valu_bench2 (tools/valu_bench2.hip) run by this bench on this GPU, 4 waves per SIMD"}
+        except Exception as e:           # a measurement aid, never a reason to fail the bench
+            live_rates = {"error": repr(e)}
     worst = None
     if world == 1 and NT >= 64 and not args.no_worst_case:
         # large triangles (clutter x10: most rays cross most cylinders): how far the two-stage scan degrades.  Untimed, after
@@ -424,12 +445,17 @@ def main():
         if cls and valu_achieved and cls.get("source_hash") == lib_hash:
             mix = {"full": cls["full_rate_frac"], "half": cls["half_rate_frac"], "trans": cls["trans_frac"]}
             cyc = sum(mix[k] * VALU_CLASS_CYCLES[k] for k in mix)                         # nominal issue cycles per wave64 instruction of this mix
-            sec_per_tinstr = sum(mix[k] / VALU_CLASS_MEASURED_TINSTR[k] for k in mix)     # seconds per 1e12 lane-instructions at the measured class rates
+            rates = dict(VALU_CLASS_MEASURED_TINSTR)
+            if live_rates and "full" in live_rates:
+                rates["full"], rates["half"] = live_rates["full"], live_rates["half"]       # this box, this run
+            sec_per_tinstr = sum(mix[k] / rates[k] for k in mix)     # seconds per 1e12 lane-instructions at the measured class rates
             issue_classes = {
                 "full_rate_frac": mix["full"], "half_rate_frac": mix["half"], "trans_frac": mix["trans"],
                 "nominal_cycles_per_instr": round(cyc, 3),
                 "frac_class_weighted": round(valu_achieved / (VALU_PEAK_TINSTR * 2.0 / cyc), 4),
                 "frac_of_measured_class_rates": round(valu_achieved * sec_per_tinstr, 4),
+                "class_rates_tinstr": {k: rates[k] for k in ("full", "half", "trans")},
+                "class_rates_source": (live_rates or {}).get("source", "profiles/r03_valu_microbench_classes.log (committed; build/valu_bench2 not present or not run)"),
                 "note": "only f32 add/mul/fma issue at the 32 lanes/clk of `peak`; min/max, integer, compare/select, bit and cross-lane instructions issue at 16 "
                         "(measured: profiles/r03_valu_microbench_classes.log).  frac_class_weighted prices every instruction at its nominal issue cycles (2 / 4 / 8); "
                         "frac_of_measured_class_rates at the rates a pure stream of each class sustains at this kernel's 4 waves per SIMD",

@@ -10,8 +10,8 @@ O=gpurun_out
 B="python3 bench.py"
 $B > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 # (--no-worst-case: the large-triangle scene is the same kernel; its one short launch would sit in the kernel's average)
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt -o p --output-format csv -- $B --no-cpu-baseline --no-worst-case > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_kt.err
-P="--steps 1 --warmup 0 --no-cpu-baseline --no-worst-case"
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt -o p --output-format csv -- $B --no-cpu-baseline --no-worst-case --no-valu-microbench > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_kt.err
+P="--steps 1 --warmup 0 --no-cpu-baseline --no-worst-case --no-valu-microbench"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/${TAG}_pmc_sq -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_sq.json 2> $O/${TAG}_pmc_sq.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $O/${TAG}_pmc_wait -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_wait.json 2> $O/${TAG}_pmc_wait.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE -d $O/${TAG}_pmc_cls -o p --output-format csv -- $B $P > $O/${TAG}_bench_pmc_cls.json 2> $O/${TAG}_pmc_cls.err
