@@ -17,6 +17,10 @@
 // 8 that four separate x cost (round 2).  It can only keep MORE than the per-triangle form (every triangle of a rejected group
 // has |gm_i| - H_i D > Dq, the condition DESIGN.md 4.2 proves safe), and stage 2 re-tests each triangle of a surviving group with
 // its own H.  The prepass orders every class by H (k_cylm_keys + sp_radix_sort.h), so Hmax ~ H_i and next to nothing is lost.
+// And the margin is FOLDED INTO THE BOUND, once per tile and ray instead of once per group (k_cylm_hmax, cylm_tile_bound):
+//     D' = D + kappa Dq  with  Hmax kappa >= 1 for every group of the tile   =>   Hmax D' >= Hmax D + Dq,
+// so  x' = fma(-Hmax, D', m),  sign(x')  -- 4 instructions per 4 pairs -- rejects only what the subtracted form rejects, and x',
+// rounded once, has the sign of the exact value.  Stage 1 is where the vector ALU is the limit: the instruction is worth 4 - 5 %.
 //
 // Scaling.  Halves hold 6e-5 .. 65504, so both sides are scaled by EXACT powers of two: S = 2^k in [2Rv, 4Rv) for lengths
 // (Rv = the scene bound of sp_filter_scan.h), s_d = 2^-e for the ray direction (largest |dir| component in [1, 2) afterwards):
@@ -75,6 +79,9 @@ static_assert(kMBlocks * 2u <= kMGroups, "the Hmax table fits chunk 7");
 SP_DEV constexpr uint32_t cylm_slot(uint32_t group, uint32_t chunk) { return chunk * kMGroups + group; }
 // scaled Hmax of the four groups 8 tb + 2 j + hh (j = 0..3) that lane half hh owns in fragment tb: component j of this float4
 SP_DEV constexpr uint32_t cylm_hmq(uint32_t tb, uint32_t hh) { return 7u * kMGroups + tb * 2u + hh; }
+// behind that table: .x = kappa of the tile, 1 / (the smallest regular Hmax^ of the tile) rounded up (k_cylm_hmax; cylm_tile_bound)
+SP_DEV constexpr uint32_t cylm_kq() { return 7u * kMGroups + kMBlocks * 2u; }
+static_assert(kMBlocks * 2u + 1u <= kMGroups, "Hmax table and kappa fit chunk 7");
 
 // length scale of the scene: the power of two in [2 Rv, 4 Rv); 0 = matrix filter off for this scene (Rv outside [1e-30, 1e30])
 SP_DEV float cylm_scale(float rv) {
@@ -227,16 +234,35 @@ __global__ void __launch_bounds__(256) k_cylm_pad(const uint32_t* __restrict__ h
 }
 
 // ---- prepass 5: Hmax^ = 256 max(H) / S of every group (one thread per group, one block per tile): +inf if the group holds a
-// degenerate triangle (always survives), -inf if it holds nothing but padding (never does)
+// degenerate triangle (always survives), -inf if it holds nothing but padding (never does) -- and kappa of the tile.
+// Stage 1 tests  min_i |g_i| - Hmax^ D' < 0  with  D' = D^ + kappa Dq^  (cylm_tile_bound): the margin Dq^ folded into the cylinder
+// bound, one instruction less per group.  It needs  Hmax^ kappa >= 1  for every regular (finite) group of the tile: then
+// Hmax^ D' >= Hmax^ D^ + Dq^, i.e. whatever this form rejects, the form with the margin subtracted rejects too.  kappa = 1 / (smallest
+// regular Hmax^).  The classes are sorted by H, so Hmax^ hardly varies inside a tile and next to nothing is lost; where it does vary
+// (or is 0: a triangle of no height), the small values are RAISED to 2^-10 of the tile's largest (a larger H only keeps more), which
+// bounds the amplification of the margin (2^-16 of the magnitudes) by 2^10.
 __global__ void __launch_bounds__(kMGroups) k_cylm_hmax(const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
-	if (blockIdx.x >= hdr[6] || threadIdx.x >= kMGroups) return;
+	__shared__ uint32_t s_max, s_min;
+	if (blockIdx.x >= hdr[6]) return;
+	if (threadIdx.x == 0) { s_max = 0u; s_min = 0x7f800000u; }
+	__syncthreads();
 	float4* tile = rec + (size_t)blockIdx.x * kMTileQ;
 	const uint32_t grp = threadIdx.x, tb = grp >> 3, j = (grp & 7u) >> 1, hh = grp & 1u;
 	const float S = ((const float*)hdr)[7];
 	const float k = S > 0.0f ? 256.0f / S : 1.0f;                                       // exact: S is a power of two
 	const float4 a = tile[cylm_slot(grp, 4u)], b = tile[cylm_slot(grp, 5u)];           // (Mz H Mz H) of triangles 0,1 and 2,3
-	const float hm = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) * k;                       // +-inf stay +-inf
+	float hm = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) * k;                             // +-inf stay +-inf
+	const bool regular = hm >= 0.0f && hm < __builtin_inff();                           // (positive floats order as their bits)
+	if (regular) atomicMax(&s_max, __float_as_uint(hm));
+	__syncthreads();
+	const float floor_ = fmaxf(__uint_as_float(s_max) * 0x1p-10f, 0x1p-60f);
+	if (regular) { hm = fmaxf(hm, floor_); atomicMin(&s_min, __float_as_uint(hm)); }
+	__syncthreads();
 	((float*)(tile + cylm_hmq(tb, hh)))[j] = hm;
+	if (threadIdx.x == 0) {
+		const float hmin = s_min == 0x7f800000u ? 1.0f : __uint_as_float(s_min);        // no regular group: any kappa will do
+		tile[cylm_kq()] = make_float4((1.0f / hmin) * (1.0f + 0x1p-20f), 0.0f, 0.0f, 0.0f);   // rounded up whatever the division does
+	}
 }
 
 SP_DEV void cylm_tile_dma(const float4* __restrict__ src, float4* dst, uint32_t tid, uint32_t wbase) {
@@ -400,37 +426,23 @@ SP_DEV float min4_abs(float a, float b, float c, float d) {
 #endif
 }
 
-// ---- stage 1 for one fragment (32 triangles) of tile `cur` against the wave's 64 rays: appends 4 bits to word[rb], one per group
-// 8 tb + 2 j + hh (j = 0..3, first appended = highest).  2 LDS reads, 2 matrix instructions, 40 VALU for 2048 pairs.
-SP_DEV void cylm_fragment(const float4* cur, uint32_t tb, uint32_t lane, const CylmRay& R, uint32_t (&word)[2]) {
-	const half8 afr = ((const half8*)(cur + kMRecQ))[tb * 64u + lane];
-	const float4 Hm = cur[cylm_hmq(tb, lane >> 5)];
-	float16v zero;
+// D' of the wave's two ray blocks for tile `cur`: D^ + kappa Dq^, rounded up (D^ > 0; Dq^ > 0, or +inf: filter off -> D' = +inf: every
+// regular group survives; or -inf: idle lane -> D' = -inf: none does).  Two instructions per ray block and TILE instead of one per group.
+SP_DEV void cylm_tile_bound(const float4* cur, const CylmRay& R, float (&Dt)[2]) {
+	const float kappa = cur[cylm_kq()].x;
 #pragma unroll
-	for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
-	const float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[0], zero, 0, 0, 0);
-	const float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[1], zero, 0, 0, 0);
-#pragma unroll
-	for (int rb = 0; rb < 2; ++rb) {
-		const float16v& g = rb == 0 ? g0 : g1;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const float hm = j == 0 ? Hm.x : j == 1 ? Hm.y : j == 2 ? Hm.z : Hm.w;
-			const float m = min4_abs(g[4 * j + 0], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
-			const float x = __builtin_fmaf(-hm, R.Dn[rb], m);
-			word[rb] = __builtin_amdgcn_alignbit(word[rb], __float_as_uint(x - R.Dqn[rb]), 31);
-		}
-	}
+	for (int rb = 0; rb < 2; ++rb) Dt[rb] = __builtin_fmaf(R.Dqn[rb], kappa, R.Dn[rb]) * (1.0f + 0x1p-22f);
 }
 
-// the VALU half of cylm_fragment for one ray block: 4 group bits from the 16 side products g and the four Hmax of the lane half
-SP_DEV uint32_t cylm_bits(const float16v& g, const float4 Hm, float Dn, float Dqn, uint32_t word) {
+// the VALU part of stage 1 for one fragment and ray block: 4 group bits from the 16 side products g and the four Hmax^ of the lane half.
+// x = fma(-Hmax^, D', min_i |g_i|) is rounded ONCE, so its sign is the sign of the exact value: four instructions per group
+// (v_minimum3 x 2, v_fma, v_alignbit).  Hmax^ > 0 or +-inf (k_cylm_hmax), D' != 0: no 0 x inf.
+SP_DEV uint32_t cylm_bits(const float16v& g, const float4 Hm, float Dt, uint32_t word) {
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		const float hm = j == 0 ? Hm.x : j == 1 ? Hm.y : j == 2 ? Hm.z : Hm.w;
 		const float m = min4_abs(g[4 * j + 0], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
-		const float x = __builtin_fmaf(-hm, Dn, m);
-		word = __builtin_amdgcn_alignbit(word, __float_as_uint(x - Dqn), 31);
+		word = __builtin_amdgcn_alignbit(word, __float_as_uint(__builtin_fmaf(-hm, Dt, m)), 31);
 	}
 	return word;
 }
@@ -439,7 +451,7 @@ SP_DEV uint32_t cylm_bits(const float16v& g, const float4 Hm, float Dn, float Dq
 // block) is issued before the 20 VALU instructions that turn the previous result into bits, and the LDS reads run a fragment
 // ahead -- an in-order wave otherwise sits through the LDS latency, both matrix instructions and their result latency before its
 // first VALU instruction of every fragment.  No extra accumulators: a ray block's 16 registers are free again when its bits are out.
-SP_DEV void cylm_stage1(const float4* cur, uint32_t tb0, uint32_t nblk, uint32_t lane, const CylmRay& R, uint32_t (&word)[2]) {
+SP_DEV void cylm_stage1(const float4* cur, uint32_t tb0, uint32_t nblk, uint32_t lane, const CylmRay& R, const float (&Dt)[2], uint32_t (&word)[2]) {
 	if (nblk == 0u) return;
 	const half8* frags = (const half8*)(cur + kMRecQ) + tb0 * 64u + lane;
 	const float4* hmq = cur + cylm_hmq(tb0, lane >> 5);
@@ -454,17 +466,17 @@ SP_DEV void cylm_stage1(const float4* cur, uint32_t tb0, uint32_t nblk, uint32_t
 		const half8 afr_n = frags[tb * 64u];
 		const float4 Hm_n = hmq[tb * 2u];
 		__builtin_amdgcn_sched_barrier(0);
-		word[0] = cylm_bits(g0, Hm, R.Dn[0], R.Dqn[0], word[0]);
+		word[0] = cylm_bits(g0, Hm, Dt[0], word[0]);
 		__builtin_amdgcn_sched_barrier(0);
 		g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_n, R.bfr[0], zero, 0, 0, 0);
 		__builtin_amdgcn_sched_barrier(0);
-		word[1] = cylm_bits(g1, Hm, R.Dn[1], R.Dqn[1], word[1]);
+		word[1] = cylm_bits(g1, Hm, Dt[1], word[1]);
 		__builtin_amdgcn_sched_barrier(0);
 		g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_n, R.bfr[1], zero, 0, 0, 0);
 		Hm = Hm_n;
 	}
-	word[0] = cylm_bits(g0, Hm, R.Dn[0], R.Dqn[0], word[0]);
-	word[1] = cylm_bits(g1, Hm, R.Dn[1], R.Dqn[1], word[1]);
+	word[0] = cylm_bits(g0, Hm, Dt[0], word[0]);
+	word[1] = cylm_bits(g1, Hm, Dt[1], word[1]);
 }
 
 constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: group << 8 | ray << 2); what does not fit waits for the next pass
@@ -593,13 +605,15 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 		}
 		const uint32_t nblk = hd.fragments(gt);
 		// ---- stage 1: word[w][rb] gets 4 bits per fragment 8 w + f (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
+		float Dt[2];
+		cylm_tile_bound(cur, R, Dt);
 		uint32_t word[kMWords][2];
 #pragma unroll
 		for (int w = 0; w < (int)kMWords; ++w) {
 			word[w][0] = word[w][1] = 0u;
 			const uint32_t tb0 = 8u * (uint32_t)w;
 			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < 8u ? nblk - tb0 : 8u) : 0u;       // fragments of this word (wave-uniform)
-			cylm_stage1(cur, tb0, nb, lane, R, word[w]);
+			cylm_stage1(cur, tb0, nb, lane, R, Dt, word[w]);
 			const uint32_t done = nb * 4u;                            // bits appended; left-align
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb) word[w][rb] = done == 0u ? 0u : (word[w][rb] << (32u - done));
@@ -774,11 +788,13 @@ __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict_
 		for (uint32_t q = lane; q < kMTileQ; q += 64u) sm[q] = cs.rec[(size_t)gt * kMTileQ + q];
 		__syncthreads();
 		const uint32_t nblk = hd.fragments(gt);
+		float Dt[2];
+		cylm_tile_bound(sm, R, Dt);
 		for (uint32_t w = 0; w < kMWords; ++w) {
 			uint32_t word[2] = { 0u, 0u };
 			const uint32_t tb0 = 8u * w;
 			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < 8u ? nblk - tb0 : 8u) : 0u;
-			cylm_stage1(sm, tb0, nb, lane, R, word);
+			cylm_stage1(sm, tb0, nb, lane, R, Dt, word);
 			const uint32_t done = nb * 4u;
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb)

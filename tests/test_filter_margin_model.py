@@ -322,17 +322,10 @@ def _matrix_pipe_x(pos, d, v0, v1, v2):
                 Dqt=(((Dq * kC) * t + extra) * F(1.0 + 2.0 ** -20)).astype(F), in_range=in_range)
 
 
-def test_grouped_bound_of_the_matrix_pipe_filter_is_conservative():
-    """Round 3's stage 1 (sp_cylm_scan.h): ONE bound per group of four triangles of a class, x = fma(-Hmax, D^, min_i |g^_i|),
-    reject the group iff x > Dq^ -- 5 VALU instructions per 4 pairs instead of 8.  Groups of four triangles of one class tested
-    against one ray (aimed at one of the four):
-      1. a rejected group contains no pair the strict evaluation accepts;
-      2. a rejected group is rejected triangle by triangle too by the per-pair form the proof (DESIGN.md 4.2/4.3) is written
-         for -- fl(m - Hmax D) <= fl(|g_i| - H_i D) because m <= |g_i|, Hmax >= H_i, D > 0 and rounding is monotone -- so the
-         grouped bound can only KEEP more;
-      3. with the group's H values close together (the prepass sorts every class by H) it keeps hardly more."""
-    rng = np.random.default_rng(80)
-    ng = 100_000
+def _groups_of_four(seed, ng):
+    """ng groups of four triangles of (mostly) one class with similar H, each group against one ray -- aimed at its first triangle or
+    borrowed from another group -- as _matrix_pipe_x sees them: (q, r) with r() reshaping a per-pair array to [ng, 4]."""
+    rng = np.random.default_rng(seed)
     pos, d, v0, v1, v2 = make_pairs(rng, ng)
     d = (d * np.where(rng.random((ng, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-3, 3, (ng, 1)))).astype(F)
     # half of the rays are borrowed from another group: they pass the four triangles at a distance (what stage 1 is there to reject)
@@ -347,8 +340,59 @@ def test_grouped_bound_of_the_matrix_pipe_filter_is_conservative():
         P4.append(pos); D4.append(d)
         V0.append((v0 + shift).astype(F)); V1.append((v0 + shift + (v1 - v0) * sc).astype(F)); V2.append((v0 + shift + (v2 - v0) * sc).astype(F))
     cat = lambda xs: np.stack(xs, axis=1).reshape(ng * 4, 3)
-    q = _matrix_pipe_x(cat(P4), cat(D4), cat(V0), cat(V1), cat(V2))
-    r = lambda x: x.reshape(ng, 4)
+    return _matrix_pipe_x(cat(P4), cat(D4), cat(V0), cat(V1), cat(V2)), (lambda x: x.reshape(ng, 4))
+
+
+def test_margin_folded_into_the_bound_rejects_no_more_than_the_subtracted_form():
+    """The shipped stage 1 (sp_cylm_scan.h, cylm_tile_bound / cylm_bits / k_cylm_hmax): the margin Dq^ is folded into the cylinder bound,
+    x' = fma(-Hmax^, D', min_i |g^_i|) with D' = fl(fl(fma(Dq^, kappa, D^)) (1 + 2^-22)) and kappa = fl(1 / Hmin)(1 + 2^-20), Hmin the
+    smallest Hmax^ of the TILE after the small ones were raised to 2^-10 of the largest; reject iff !(x' < 0) -- four instructions
+    per group.  Because Hmax^ kappa >= 1, Hmax^ D' >= Hmax^ D^ + Dq^, and x' is rounded once (its sign is exact):
+      1. a rejected group contains no pair the strict evaluation accepts;
+      2. whatever this form rejects, the form with the margin subtracted (previous test; the one DESIGN.md 4.2/4.3 proves) rejects too;
+      3. in tiles of an H-sorted stream it keeps hardly more."""
+    ng, G = 96_000, 64                                                   # 64 groups = one 256-triangle tile
+    q, r = _groups_of_four(81, ng)
+    same = (r(q["cls"]) == r(q["cls"])[:, :1]).all(axis=1)
+    m = np.abs(r(q["g"])).min(axis=1)
+    Hmax = r(q["Hh"]).max(axis=1)
+    Dt, Dqt = r(q["Dt"])[:, 0], r(q["Dqt"])[:, 0]
+    ok = np.isfinite(Hmax) & r(q["in_range"])[:, 0] & same
+    rej_old = ~((fma(-Hmax, Dt, m) - Dqt) < 0) & ok
+    acc = r(q["acc"])
+    for order, worst_lost in ((np.argsort(Hmax, kind="stable"), 0.02), (np.arange(ng), 0.6)):      # the prepass's H-sorted stream; an unsorted one
+        Hm = Hmax[order].reshape(-1, G).copy()
+        top = np.where(np.isfinite(Hm), Hm, F(0)).max(axis=1, keepdims=True)
+        floor_ = np.maximum((top * F(2.0 ** -10)).astype(F), F(2.0 ** -60))
+        Hm = np.where(np.isfinite(Hm), np.maximum(Hm, floor_), Hm).astype(F)
+        hmin = np.where(np.isfinite(Hm), Hm, F(np.inf)).min(axis=1, keepdims=True)
+        kappa = ((F(1.0) / hmin).astype(F) * F(1.0 + 2.0 ** -20)).astype(F)
+        assert (Hm.astype(np.float64) * kappa.astype(np.float64) >= 1.0)[np.isfinite(Hm)].all()
+        Dn, Dq, mm = Dt[order].reshape(-1, G), Dqt[order].reshape(-1, G), m[order].reshape(-1, G)
+        Dp = (fma(Dq, np.broadcast_to(kappa, Dq.shape).astype(F), Dn) * F(1.0 + 2.0 ** -22)).astype(F)
+        assert (Dp.astype(np.float64) >= Dn.astype(np.float64) + Dq.astype(np.float64) * kappa.astype(np.float64))[np.isfinite(Dp)].all()
+        xs = fma(-Hm, Dp, mm)
+        rej_new = np.zeros(ng, dtype=bool)
+        rej_new[order] = (~(xs < 0) & np.isfinite(xs)).reshape(-1)
+        rej_new &= ok
+        assert not (rej_new[:, None] & acc).any(), int((rej_new[:, None] & acc).sum())        # 1.
+        assert not (rej_new & ~rej_old).any(), int((rej_new & ~rej_old).sum())                # 2.
+        lost = 1.0 - rej_new.sum() / max(rej_old.sum(), 1)
+        assert lost < worst_lost, lost                                                          # 3.
+        print(f"margin folded into the bound: rejects {rej_new.mean():.4f} of the groups, the subtracted form {rej_old.mean():.4f} ({lost:.3%} kept in addition)")
+
+
+def test_grouped_bound_of_the_matrix_pipe_filter_is_conservative():
+    """Round 3's grouped bound (sp_cylm_scan.h): ONE bound per group of four triangles of a class, x = fma(-Hmax, D^, min_i |g^_i|),
+    reject the group iff x > Dq^ (the shipped kernel folds Dq^ into D^: test above).  Groups of four triangles of one class tested
+    against one ray (aimed at one of the four):
+      1. a rejected group contains no pair the strict evaluation accepts;
+      2. a rejected group is rejected triangle by triangle too by the per-pair form the proof (DESIGN.md 4.2/4.3) is written
+         for -- fl(m - Hmax D) <= fl(|g_i| - H_i D) because m <= |g_i|, Hmax >= H_i, D > 0 and rounding is monotone -- so the
+         grouped bound can only KEEP more;
+      3. with the group's H values close together (the prepass sorts every class by H) it keeps hardly more."""
+    ng = 100_000
+    q, r = _groups_of_four(80, ng)
     same = (r(q["cls"]) == r(q["cls"])[:, :1]).all(axis=1)           # groups of one class (the stream is class-sorted)
     assert same.mean() > 0.5
     # the scaled ray values depend on the ray and the class only
