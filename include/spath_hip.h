@@ -197,14 +197,16 @@ int sphip_selftest_device(sphip_t* ctx, int what, const void* in, size_t n, void
  * geom::ray_intersect (src/geom.h:197-222) -- for n_rays host rays (a multiple of 64) against the context's scene, formed
  * exactly as the render kernels form it (same ray setup, same fragment code, same tiles).  A test can then assert, pair by
  * pair, that no pair the reference accepts has its bit clear, instead of observing the filter only through the closest hit.
- *   *tiles_out         bits 0-19: tiles of the scene's stream, bits 20-31: T = triangles per tile (call with out_words = NULL first
- *                      to size the outputs); W = T / 256 words per ray block below
- *   out_words[((k * tiles + t) * 2 + rb) * W + w]   word w of "lane" k (k = 64 b + l) for tile t: bit 31 - (4 f + j) set = the group of four
- *                      triangles 8 (8 w + f) + 2 j + (l >> 5) of tile t SURVIVES for ray 64 b + (l & 31) + 32 rb (f < 8, j < 4)
+ *   *tiles_out         bits 0-19: tiles of the scene's stream, bits 20-30: T = triangles per tile, bit 31: one survivor bit per OCTET (two groups
+ *                      of four) instead of per group of four (call with out_words = NULL first to size the outputs); W words per ray block
+ *                      below: T / 256 with group bits, max(1, T / 512) with octet bits
+ *   out_words[((k * tiles + t) * 2 + rb) * W + w]   word w of "lane" k (k = 64 b + l) for tile t.  Group bits: bit 31 - (4 f + j) set = the group of
+ *                      four triangles 8 (8 w + f) + 2 j + (l >> 5) of tile t SURVIVES for ray 64 b + (l & 31) + 32 rb (f < 8, j < 4).  Octet bits:
+ *                      bit 31 - (2 f + q) set = the groups 8 (16 w + f) + 4 q + (l >> 5) and that + 2 survive (f < 16, q < 2)
  *   out_tri[((k * tiles + t) * 2 + rb) * (T / 64) + f / 2]   (may be NULL) the same side products tested per TRIANGLE with the triangle's own
  *                      cylinder radius (the per-pair form of the test): bit 31 - (16 (f & 1) + 4 j + i) set = triangle
- *                      32 f + 8 j + 4 (l >> 5) + i of tile t survives for that ray (f < T / 32).  Stronger than the group bit: a set
- *                      triangle bit implies the set group bit
+ *                      32 f + 8 j + 4 (l >> 5) + i of tile t survives for that ray (f < T / 32).  Stronger than the group / octet bit: a set
+ *                      triangle bit implies the set bit of its group / octet
  *   out_order[t * T + 4 g + u]            index of the triangle at place u of group g of tile t (n_tris = padding; a triangle that
  *                      appears nowhere is in the "big" class: no filter, tested by every ray)
  * Blocking; host pointers; single-device contexts. */

@@ -294,7 +294,8 @@ class Context:
     def selftest_stage1(self, rays, per_triangle=True):
         """sphip_selftest_stage1 (test-only): stage 1 of the default scan alone for the given rays (padded to a multiple of 64)
         against the context's scene.  Returns (group_survives, tri_survives, order): both [ray, stream position] bool -- the
-        position's group of four survives the grouped bound / the triangle itself survives the per-pair form of the test
+        position's OCTET (its group of four and the partner group two further on) survives the bound of the octet / the triangle itself survives
+        the per-pair form of the test
         (None unless per_triangle) -- and order[stream position] = triangle index (n_tris = padding)."""
         import numpy as np
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
@@ -304,23 +305,30 @@ class Context:
             rays = np.concatenate([rays, np.repeat(rays[-1:], n_pad - n, axis=0)])
         tiles = C.c_uint32(0)
         self._check(self._L.sphip_selftest_stage1(self._h, None, 0, None, None, None, C.byref(tiles)), "sphip_selftest_stage1")
-        t, T = tiles.value & 0xFFFFF, tiles.value >> 20
-        W, G = T // 256, T // 4                                          # words per ray block, groups per tile
+        t, T, octets = tiles.value & 0xFFFFF, (tiles.value >> 20) & 0x7FF, bool(tiles.value >> 31)
+        G = T // 4                                                       # groups of four per tile
+        W = max(1, T // 512) if octets else T // 256                     # words per ray block: 2 (octets) or 4 (groups) bits per fragment
         words = np.zeros(n_pad * t * 2 * W, dtype=np.uint32)
         tri = np.zeros(n_pad * t * 2 * (T // 64), dtype=np.uint32) if per_triangle else None
         order = np.zeros(t * T, dtype=np.int32)
         self._check(self._L.sphip_selftest_stage1(self._h, rays.ctypes.data, n_pad, words.ctypes.data, tri.ctypes.data if per_triangle else None,
                                                   order.ctypes.data, C.byref(tiles)), "sphip_selftest_stage1")
         nb = n_pad // 64
-        # words[(64 b + l), tile, rb, w]: bit 31 - (4 f + j) <-> group 8 (8 w + f) + 2 j + (l >> 5), ray 64 b + (l & 31) + 32 rb
+        # words[(64 b + l), tile, rb, w], bit 31 - k, ray 64 b + (l & 31) + 32 rb:
+        #   group bits:  k = 4 f + j <-> group 8 (8 w + f) + 2 j + (l >> 5) = 64 w + 2 k + (l >> 5)
+        #   octet bits:  k = 2 f + q <-> groups g = 8 (16 w + f) + 4 q + (l >> 5) = 128 w + 4 k + (l >> 5) and g + 2
         w = words.reshape(nb, 2, 32, t, 2, W)                            # [block, half, column, tile, rb, word]
-        bits = ((w[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)     # [..., k = 4 f + j]
+        bits = ((w[..., None] >> (31 - np.arange(32, dtype=np.uint32))) & 1).astype(bool)     # [..., k]
         wi, k = np.meshgrid(np.arange(W), np.arange(32), indexing="ij")
-        surv = np.zeros((nb, 64, t, G), dtype=bool)                      # [block, ray in block, tile, group]
+        surv = np.zeros((nb, 64, t, G), dtype=bool)                      # [block, ray in block, tile, group of four]
         for hh in range(2):
-            grp = (64 * wi + 2 * k + hh).reshape(-1)                     # 8 (8 w + k // 4) + 2 (k % 4) + hh
+            g0 = ((128 * wi + 4 * k if octets else 64 * wi + 2 * k) + hh).reshape(-1)
+            keep = g0 + (2 if octets else 0) < G                         # (a 256-triangle tile with octet bits uses the upper half of its one word)
             for rb in range(2):
-                surv[:, 32 * rb:32 * rb + 32, :, grp] = bits[:, hh, :, :, rb].reshape(nb, 32, t, W * 32)
+                b = bits[:, hh, :, :, rb].reshape(nb, 32, t, W * 32)[..., keep]
+                surv[:, 32 * rb:32 * rb + 32, :, g0[keep]] = b
+                if octets:
+                    surv[:, 32 * rb:32 * rb + 32, :, g0[keep] + 2] = b
         surv = np.repeat(surv.reshape(n_pad, t * G), 4, axis=1)          # per stream position
         tsurv = None
         if per_triangle:

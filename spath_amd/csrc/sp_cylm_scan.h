@@ -44,8 +44,8 @@
 // ray block (128 / 192-triangle tiles: -15 % / -4 %).  Build hooks for experiments: SP_EXP_NO_STAGE2 (timing only), SP_DBG_ALLBITS, SP_DBG_PRINT, SP_CYLM_UNPINNED.
 //
 // THIS FILE IS INCLUDED TWICE (sp_cylm_both.h): once per workgroup shape, each copy in a namespace of its own --
-//   sp::cylm256   256 threads, 256-triangle tiles (four workgroups per CU)     scenes below kMBigSceneTris triangles
-//   sp::cylm512   512 threads, 512-triangle tiles (two workgroups per CU)      larger scenes
+//   sp::cylm256   256 threads, 256-triangle tiles (four workgroups per CU), one survivor bit per group of four     scenes below kMBigSceneTris triangles
+//   sp::cylm512   512 threads, 512-triangle tiles (two workgroups per CU), one survivor bit per OCTET (kMGrp = 8)   larger scenes
 // Larger tiles halve what a tile costs beyond its pairs (LDS-DMA issue, barrier, list pass, the half-filled last round of stage 2):
 // +7 % at 10^5 and +8 % at 10^6 triangles; eight waves per barrier wait longer for their slowest member, which costs more than that
 // where stage 2 is heavy: -2 % at 10^4 triangles, -20 % on the large-triangle scene (profiles/r03_cyl_scan_experiments.log).
@@ -69,7 +69,17 @@ constexpr uint32_t kMWaves = kMThreads / 64u;
 constexpr uint32_t kMTile = SP_CYLM_TILE;        // triangles per tile
 constexpr uint32_t kMGroups = kMTile / 4u;        // 128 groups of four
 constexpr uint32_t kMBlocks = kMTile / 32u;       // 16 fragments
-constexpr uint32_t kMWords = (kMBlocks * 4u + 31u) / 32u;     // 32-bit words of group bits per ray block and tile (4 bits per fragment)
+// Stage 1 keeps ONE bit per (ray, kMGrp triangles): per QUAD (the group of four, 8 tb + 2 j + hh) or per OCTET (two quads: 8 tb + 4 q + hh and
+// that + 2, q = 0, 1).  Octets: 6 instead of 8 vector instructions per eight pairs in stage 1, but eight re-tests per list entry in stage 2 --
+// measured: +4 % / +8 % at 10^5 / 10^6 triangles, -8 % at 10^4 (more entries per tile there): quads for the 256-thread shape, octets for the 512-thread one.
+#ifndef SP_CYLM_GROUP
+#define SP_CYLM_GROUP 4
+#endif
+constexpr uint32_t kMGrp = SP_CYLM_GROUP;
+static_assert(kMGrp == 4u || kMGrp == 8u, "quads or octets (all sixteen rows of a lane as one group: -8 % / -4 % at 10^5 / 10^6 triangles against octets)");
+constexpr uint32_t kMBitsFrag = 16u / kMGrp;                 // bits per fragment and lane half
+constexpr uint32_t kMFragsPerWord = 32u / kMBitsFrag;
+constexpr uint32_t kMWords = (kMBlocks * kMBitsFrag + 31u) / 32u;     // 32-bit words of survivor bits per ray block and tile
 constexpr uint32_t kMRecQ = kMGroups * 8u;        // 1024 float4: the f32 part
 constexpr uint32_t kMTileQ = kMRecQ + kMBlocks * 64u;   // 2048 float4 = 32 KB
 static_assert(kMThreads % 64u == 0u && kMThreads <= 1024u, "whole waves");
@@ -243,24 +253,29 @@ __global__ void __launch_bounds__(256) k_cylm_pad(const uint32_t* __restrict__ h
 // bounds the amplification of the margin (2^-16 of the magnitudes) by 2^10.
 __global__ void __launch_bounds__(kMGroups) k_cylm_hmax(const uint32_t* __restrict__ hdr, float4* __restrict__ rec) {
 	__shared__ uint32_t s_max, s_min;
+	__shared__ float s_h[kMGroups];
 	if (blockIdx.x >= hdr[6]) return;
 	if (threadIdx.x == 0) { s_max = 0u; s_min = 0x7f800000u; }
-	__syncthreads();
 	float4* tile = rec + (size_t)blockIdx.x * kMTileQ;
 	const uint32_t grp = threadIdx.x, tb = grp >> 3, j = (grp & 7u) >> 1, hh = grp & 1u;
 	const float S = ((const float*)hdr)[7];
 	const float k = S > 0.0f ? 256.0f / S : 1.0f;                                       // exact: S is a power of two
 	const float4 a = tile[cylm_slot(grp, 4u)], b = tile[cylm_slot(grp, 5u)];           // (Mz H Mz H) of triangles 0,1 and 2,3
-	float hm = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) * k;                             // +-inf stay +-inf
+	s_h[grp] = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)) * k;                             // the group of four; +-inf stay +-inf
+	__syncthreads();
+	// octets: this quad and its partner (grp ^ 2: the other j of the same q and lane half); both threads hold the same value
+	float hm = kMGrp == 8u ? fmaxf(s_h[grp], s_h[grp ^ 2u]) : s_h[grp];
 	const bool regular = hm >= 0.0f && hm < __builtin_inff();                           // (positive floats order as their bits)
 	if (regular) atomicMax(&s_max, __float_as_uint(hm));
 	__syncthreads();
 	const float floor_ = fmaxf(__uint_as_float(s_max) * 0x1p-10f, 0x1p-60f);
 	if (regular) { hm = fmaxf(hm, floor_); atomicMin(&s_min, __float_as_uint(hm)); }
 	__syncthreads();
-	((float*)(tile + cylm_hmq(tb, hh)))[j] = hm;
+	// the float4 of (fragment, lane half): component j of a quad; components q = 0, 1 of an octet (written by its first quad: j even)
+	if (kMGrp == 4u) ((float*)(tile + cylm_hmq(tb, hh)))[j] = hm;
+	else if ((j & 1u) == 0u) ((float*)(tile + cylm_hmq(tb, hh)))[j >> 1] = hm;
 	if (threadIdx.x == 0) {
-		const float hmin = s_min == 0x7f800000u ? 1.0f : __uint_as_float(s_min);        // no regular group: any kappa will do
+		const float hmin = s_min == 0x7f800000u ? 1.0f : __uint_as_float(s_min);        // no regular octet: any kappa will do
 		tile[cylm_kq()] = make_float4((1.0f / hmin) * (1.0f + 0x1p-20f), 0.0f, 0.0f, 0.0f);   // rounded up whatever the division does
 	}
 }
@@ -434,15 +449,34 @@ SP_DEV void cylm_tile_bound(const float4* cur, const CylmRay& R, float (&Dt)[2])
 	for (int rb = 0; rb < 2; ++rb) Dt[rb] = __builtin_fmaf(R.Dqn[rb], kappa, R.Dn[rb]) * (1.0f + 0x1p-22f);
 }
 
-// the VALU part of stage 1 for one fragment and ray block: 4 group bits from the 16 side products g and the four Hmax^ of the lane half.
-// x = fma(-Hmax^, D', min_i |g_i|) is rounded ONCE, so its sign is the sign of the exact value: four instructions per group
-// (v_minimum3 x 2, v_fma, v_alignbit).  Hmax^ > 0 or +-inf (k_cylm_hmax), D' != 0: no 0 x inf.
+// min |.| of eight matrix-pipe results: four v_minimum3_f32 (see min4_abs for why not fminf)
+SP_DEV float min8_abs(float a, float b, float c, float d, float e, float f, float g, float h) {
+	typedef float T;
+	const T m1 = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+	const T m2 = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_fabsf(d), __builtin_fabsf(e)), __builtin_fabsf(f));
+	const T m3 = __builtin_elementwise_minimum(__builtin_elementwise_minimum(m1, __builtin_fabsf(g)), __builtin_fabsf(h));
+	return __builtin_elementwise_minimum(m3, m2);
+}
+
+// the VALU part of stage 1 for one fragment and ray block: the survivor bits from the 16 side products g and the Hmax^ of the lane half --
+// 4 quad bits (j = 0..3: rows 4 j .. 4 j + 3 of the lane's 16) or 2 octet bits (q = 0, 1: rows 8 q .. 8 q + 7).  x = fma(-Hmax^, D', min_i |g_i|)
+// is rounded ONCE, so its sign is the sign of the exact value: v_minimum3 x 2, v_fma, v_alignbit per quad (1 per pair), v_minimum3 x 4, v_fma,
+// v_alignbit per octet (0.75 per pair).  Hmax^ > 0 or +-inf (k_cylm_hmax), D' != 0: no 0 x inf.
 SP_DEV uint32_t cylm_bits(const float16v& g, const float4 Hm, float Dt, uint32_t word) {
+	if constexpr (kMGrp == 4u) {
 #pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const float hm = j == 0 ? Hm.x : j == 1 ? Hm.y : j == 2 ? Hm.z : Hm.w;
-		const float m = min4_abs(g[4 * j + 0], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
-		word = __builtin_amdgcn_alignbit(word, __float_as_uint(__builtin_fmaf(-hm, Dt, m)), 31);
+		for (int j = 0; j < 4; ++j) {
+			const float hm = j == 0 ? Hm.x : j == 1 ? Hm.y : j == 2 ? Hm.z : Hm.w;
+			const float m = min4_abs(g[4 * j + 0], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]);
+			word = __builtin_amdgcn_alignbit(word, __float_as_uint(__builtin_fmaf(-hm, Dt, m)), 31);
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const float hm = q == 0 ? Hm.x : Hm.y;
+			const float m = min8_abs(g[8 * q + 0], g[8 * q + 1], g[8 * q + 2], g[8 * q + 3], g[8 * q + 4], g[8 * q + 5], g[8 * q + 6], g[8 * q + 7]);
+			word = __builtin_amdgcn_alignbit(word, __float_as_uint(__builtin_fmaf(-hm, Dt, m)), 31);
+		}
 	}
 	return word;
 }
@@ -604,17 +638,18 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 			R.build(hd.cls, lane);
 		}
 		const uint32_t nblk = hd.fragments(gt);
-		// ---- stage 1: word[w][rb] gets 4 bits per fragment 8 w + f (groups 8 tb + 2 j + hh, j = 0..3), first appended = highest
+		// ---- stage 1: word[w][rb] gets kMBitsFrag bits per fragment kMFragsPerWord w + f (quads j = 0..3: groups 8 tb + 2 j + hh; octets q = 0, 1:
+		// groups 8 tb + 4 q + hh and that + 2), first appended = highest
 		float Dt[2];
 		cylm_tile_bound(cur, R, Dt);
 		uint32_t word[kMWords][2];
 #pragma unroll
 		for (int w = 0; w < (int)kMWords; ++w) {
 			word[w][0] = word[w][1] = 0u;
-			const uint32_t tb0 = 8u * (uint32_t)w;
-			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < 8u ? nblk - tb0 : 8u) : 0u;       // fragments of this word (wave-uniform)
+			const uint32_t tb0 = kMFragsPerWord * (uint32_t)w;
+			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < kMFragsPerWord ? nblk - tb0 : kMFragsPerWord) : 0u;       // fragments of this word (wave-uniform)
 			cylm_stage1(cur, tb0, nb, lane, R, Dt, word[w]);
-			const uint32_t done = nb * 4u;                            // bits appended; left-align
+			const uint32_t done = nb * kMBitsFrag;                    // bits appended; left-align
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb) word[w][rb] = done == 0u ? 0u : (word[w][rb] << (32u - done));
 #ifdef SP_DBG_ALLBITS
@@ -647,10 +682,11 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 #pragma unroll
 				for (int rb = 0; rb < 2; ++rb) {
 					uint32_t m = word[w][rb];
-					const uint32_t eb = (((lane & 31u) + 32u * (uint32_t)rb) << 2) | ((64u * (uint32_t)w + hh) << 8);
+					// bit e of word w: (first) group 64 w + 2 e + hh of a quad, 128 w + 4 e + hh of an octet
+					const uint32_t eb = (((lane & 31u) + 32u * (uint32_t)rb) << 2) | ((16u * kMGrp * (uint32_t)w + hh) << 8);
 					while (m != 0u) {
 						const uint32_t e = (uint32_t)__builtin_clz(m);
-						mylst[j++] = (unsigned short)(eb + (e << 9));       // (indexed: behind a walking pointer hipcc no longer knows the list from the tile an LDS-DMA is filling)
+						mylst[j++] = (unsigned short)(eb + (e << (kMGrp == 8u ? 10 : 9)));       // (indexed: behind a walking pointer hipcc no longer knows the list from the tile an LDS-DMA is filling)
 						m &= ~(0x80000000u >> e);
 					}
 					word[w][rb] = 0u;
@@ -665,7 +701,7 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				while (__any(m != 0u && j < jend)) {
 					if (m != 0u && j < jend) {
 						const uint32_t e = (uint32_t)__builtin_clz(m);                      // e-th appended bit of word w: fragment 8 w + e / 4, j = e % 4
-						mylst[j++] = (unsigned short)((ray << 2) | ((64u * (uint32_t)w + 2u * e + hh) << 8));     // group 8 tb + 2 j + hh = 64 w + 2 e + hh
+						mylst[j++] = (unsigned short)((ray << 2) | ((16u * kMGrp * (uint32_t)w + (kMGrp / 2u) * e + hh) << 8));
 						m &= ~(0x80000000u >> e);
 					}
 				}
@@ -687,25 +723,29 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 				const float dx = wave_fetch(la, s.dir[0].x), dy = wave_fetch(la, s.dir[0].y), dz = wave_fetch(la, s.dir[0].z);
 				const float Pa = wave_fetch(la, f.Pa[0]), Pb = wave_fetch(la, f.Pb[0]), Pc = wave_fetch(la, f.Pc[0]);
 				const float D = wave_fetch(la, f.D[0]), Dq = wave_fetch(la, f.Dq[0]);
-				// the f32 cylinder test of sp_cyl_scan.h on the group's four records, each with its own H: which of them survive.  The SIGN of
-				// x - Dq, shifted in as in stage 1 (bit 3 - u = triangle u): one half-rate instruction per triangle instead of compare, mask,
-				// select and or.  (survive <=> !(x - Dq >= 0); where the difference is a NaN -- inf - inf: padding records under a ray whose
-				// filter is off, or an idle lane -- either answer is right.)
+				// the f32 cylinder test of sp_cyl_scan.h on the entry's kMGrp records (group grp; for an octet grp + 2 as well), each with its own H:
+				// which of them survive.  The SIGN of x - Dq, shifted in as in stage 1 (bit kMGrp - 1 - u = triangle u = 4 (second group) + place):
+				// one half-rate instruction per triangle instead of compare, mask, select and or.  (survive <=> !(x - Dq >= 0); where the difference
+				// is a NaN -- inf - inf: padding records under a ray whose filter is off, or an idle lane -- either answer is right.)
 				uint32_t cand = 0;
-				const CylmGroup G = cylm_group(cur, grp);
 #pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const float mz = u == 0 ? G.mh01.x : u == 1 ? G.mh01.z : u == 2 ? G.mh23.x : G.mh23.z;
-					const float Hh = u == 0 ? G.mh01.y : u == 1 ? G.mh01.w : u == 2 ? G.mh23.y : G.mh23.w;
-					const float x = cyl_x(G.q0[u], mz, Hh, Pa, Pb, Pc, -dx, -dy, -dz, D);
-					cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(x - Dq), 31);
+				for (int h = 0; h < (int)(kMGrp / 4u); ++h) {
+					const CylmGroup G = cylm_group(cur, grp + 2u * (uint32_t)h);
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const float mz = u == 0 ? G.mh01.x : u == 1 ? G.mh01.z : u == 2 ? G.mh23.x : G.mh23.z;
+						const float Hh = u == 0 ? G.mh01.y : u == 1 ? G.mh01.w : u == 2 ? G.mh23.y : G.mh23.w;
+						const float x = cyl_x(G.q0[u], mz, Hh, Pa, Pb, Pc, -dx, -dy, -dz, D);
+						cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(x - Dq), 31);
+					}
 				}
 				cand = ok ? cand : 0u;
 				SP_PH_STAMP(ph_t1); SP_PH_ADD(ph_retest, ph_t0, ph_t1);
 				// ---- (b): the candidates go on the wave's stack; a full batch of 64 is tested as soon as the next ones would not fit
-				// one pass per candidate RANK, not per place in the group: a lane's first candidate, then its second, ... (1.04 candidates
-				// per entry: the second pass is short and the third and fourth hardly ever run).  The triangle index is read from the
-				// record (one 4-byte LDS read) when its place is known, instead of all four read and selected.
+				// one pass per candidate RANK, not per place in the octet: a lane's first candidate, then its second, ... (about one candidate
+				// per entry: the second pass is short and the later ones hardly ever run).  The triangle index is read from the record (one
+				// 4-byte LDS read) when its place is known: bit k = place 3 - (k & 3) of the LAST group minus k >> 2 groups-of-the-entry; the index
+				// rows of consecutive groups are consecutive float4, so that of grp + 2 starts 8 words behind that of grp.
 				const uint32_t* const gidx = (const uint32_t*)(cur + cylm_slot(grp, 6u));
 				const uint32_t lhi = la << (kMIdxBits - 2u);                       // ray << kMIdxBits
 				for (;;) {
@@ -714,8 +754,9 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 					if (mk == 0ull) break;
 					const uint32_t cnt = (uint32_t)__popcll(mk);
 					if (q2n + cnt > kMQ2) exact_batch(64u);                  // q2n > kMQ2 - 64 >= 64 here
-					const uint32_t k = mine ? (uint32_t)__builtin_ctz(cand) : 3u;    // bit k = triangle 3 - k
-					const uint32_t idx = gidx[3u - k];
+					const uint32_t k = mine ? (uint32_t)__builtin_ctz(cand) : kMGrp - 1u;
+					const uint32_t u = kMGrp - 1u - k;                                  // triangle u of the entry: place u & 3 of its group u >> 2
+					const uint32_t idx = gidx[8u * (u >> 2) + (u & 3u)];
 					if (mine) myq2[q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = lhi | idx;
 					q2n += cnt;
 					cand &= cand - 1u;
@@ -760,11 +801,11 @@ SP_DEV void scan_cylm(const KArgs& a, const CylStream cs, float rv, const RaySlo
 
 // ---- test-only (sphip_selftest_stage1): stage 1 ALONE, exactly as scan_cylm runs it (same ray setup, same fragment function,
 // same tiles), for 64 rays per one-wave workgroup (n_rays a multiple of 64).  T = kMTile triangles per tile, W = kMWords words per ray block.
-// out_words[(((block * 64 + lane) * tiles + tile) * 2 + rb) * W + w] = the lane's word w: bit 31 - (4 f + j) = group 8 (8 w + f) + 2 j + (lane >> 5)
-// of that tile survives for ray 64 block + (lane & 31) + 32 rb.
+// out_words[(((block * 64 + lane) * tiles + tile) * 2 + rb) * W + w] = the lane's word w.  Quads: bit 31 - (4 f + j) = group 8 (8 w + f) + 2 j + (lane >> 5);
+// octets: bit 31 - (2 f + q) = the groups 8 (16 w + f) + 4 q + (lane >> 5) and that + 2 -- of that tile survives for ray 64 block + (lane & 31) + 32 rb.
 // out_tri (optional): the same side products g tested PER TRIANGLE with the triangle's own scaled H (x = fma(-H^, D^, |g|), sign(x - Dq^)):
 // out_tri[(((block * 64 + lane) * tiles + tile) * 2 + rb) * (T / 64) + tb / 2], bit 31 - (16 (tb & 1) + 4 j + i) = triangle 32 tb + 8 j + 4 (lane >> 5) + i.
-// A group bit may be set where none of its triangle bits is (the group bound is weaker), never the other way round.
+// A quad / octet bit may be set where none of its triangle bits is (its bound is weaker), never the other way round.
 // Block 0 also writes the stream order: out_order[tile * T + 4 group + u] = triangle index at that place (n_tris = padding).
 __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict__ rays, uint32_t n_rays, const CylStream cs, const unsigned int* __restrict__ bounds,
                                                       uint32_t* __restrict__ out_words, uint32_t* __restrict__ out_tri, int* __restrict__ out_order) {
@@ -792,10 +833,10 @@ __global__ void __launch_bounds__(64) k_selftest_stage1(const float* __restrict_
 		cylm_tile_bound(sm, R, Dt);
 		for (uint32_t w = 0; w < kMWords; ++w) {
 			uint32_t word[2] = { 0u, 0u };
-			const uint32_t tb0 = 8u * w;
-			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < 8u ? nblk - tb0 : 8u) : 0u;
+			const uint32_t tb0 = kMFragsPerWord * w;
+			const uint32_t nb = nblk > tb0 ? (nblk - tb0 < kMFragsPerWord ? nblk - tb0 : kMFragsPerWord) : 0u;
 			cylm_stage1(sm, tb0, nb, lane, R, Dt, word);
-			const uint32_t done = nb * 4u;
+			const uint32_t done = nb * kMBitsFrag;
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb)
 				if (k < n_rays) out_words[(((size_t)k * total_tiles + gt) * 2u + (uint32_t)rb) * kMWords + w] = done == 0u ? 0u : (word[rb] << (32u - done));

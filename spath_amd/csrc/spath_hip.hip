@@ -1071,7 +1071,8 @@ int sphip_selftest_stage1(sphip_t* c, const float* rays, size_t n_rays, uint32_t
 	HIP_TRY(c, hipStreamSynchronize(st));
 	const uint32_t tiles = hdr[6];
 	const uint32_t T = c->cylm_wide ? sp::cylm512::kMTile : sp::cylm256::kMTile, W = c->cylm_wide ? sp::cylm512::kMWords : sp::cylm256::kMWords;
-	*tiles_out = tiles | (T << 20);                        // tiles of the stream (low 20 bits) and triangles per tile
+	const uint32_t grp8 = (c->cylm_wide ? sp::cylm512::kMGrp : sp::cylm256::kMGrp) == 8u ? 1u : 0u;
+	*tiles_out = tiles | (T << 20) | (grp8 << 31);         // tiles of the stream (low 20 bits), triangles per tile, bit 31: one bit per octet (else per quad)
 	if (!out_words) return SPHIP_OK;
 	if (!rays || !out_order || n_rays == 0 || n_rays % 64 || n_rays > 0x7fffffffull) return fail(c, SPHIP_E_INVALID, "bad stage-1 selftest arguments (n_rays=%zu)", n_rays);
 	const size_t words_b = n_rays * tiles * 2 * W * sizeof(uint32_t), tri_b = n_rays * tiles * 2 * (T / 64) * sizeof(uint32_t),

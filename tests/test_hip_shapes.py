@@ -36,7 +36,7 @@ def _tiles(ctx, rays):
     import ctypes as C
     t = C.c_uint32(0)
     ctx._check(ctx._L.sphip_selftest_stage1(ctx._h, None, 0, None, None, None, C.byref(t)), "sphip_selftest_stage1")
-    return t.value & 0xFFFFF, t.value >> 20
+    return t.value & 0xFFFFF, (t.value >> 20) & 0x7FF            # (bit 31: octet bits)
 
 
 def test_forced_shape_closest_hits_and_renders(shaped, O):
