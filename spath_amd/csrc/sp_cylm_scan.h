@@ -492,25 +492,36 @@ SP_DEV void cylm_stage1(const float4* cur, uint32_t tb0, uint32_t nblk, uint32_t
 	float16v zero;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
-	half8 afr = frags[0];
-	float4 Hm = hmq[0];
-	float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[0], zero, 0, 0, 0);
-	float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, R.bfr[1], zero, 0, 0, 0);
-	for (uint32_t tb = 1; tb < nblk; ++tb) {
-		const half8 afr_n = frags[tb * 64u];
-		const float4 Hm_n = hmq[tb * 2u];
-		__builtin_amdgcn_sched_barrier(0);
-		word[0] = cylm_bits(g0, Hm, Dt[0], word[0]);
-		__builtin_amdgcn_sched_barrier(0);
-		g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_n, R.bfr[0], zero, 0, 0, 0);
-		__builtin_amdgcn_sched_barrier(0);
-		word[1] = cylm_bits(g1, Hm, Dt[1], word[1]);
-		__builtin_amdgcn_sched_barrier(0);
-		g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_n, R.bfr[1], zero, 0, 0, 0);
-		Hm = Hm_n;
+	// two fragments per trip, their operands in two named sets (A, B): no register copies from "next" to "current", one pair of address
+	// increments and one branch per two fragments
+#define SP_S1_STEP(afr_cur_Hm, afr_next)                                                     \
+		__builtin_amdgcn_sched_barrier(0);                                                   \
+		word[0] = cylm_bits(g0, afr_cur_Hm, Dt[0], word[0]);                                 \
+		__builtin_amdgcn_sched_barrier(0);                                                   \
+		g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_next, R.bfr[0], zero, 0, 0, 0);      \
+		__builtin_amdgcn_sched_barrier(0);                                                   \
+		word[1] = cylm_bits(g1, afr_cur_Hm, Dt[1], word[1]);                                 \
+		__builtin_amdgcn_sched_barrier(0);                                                   \
+		g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr_next, R.bfr[1], zero, 0, 0, 0);
+	half8 afrA = frags[0], afrB;
+	float4 HmA = hmq[0], HmB;
+	float16v g0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrA, R.bfr[0], zero, 0, 0, 0);
+	float16v g1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrA, R.bfr[1], zero, 0, 0, 0);
+	uint32_t tb = 1;
+	for (; tb + 1u < nblk; tb += 2u) {
+		afrB = frags[tb * 64u]; HmB = hmq[tb * 2u];
+		SP_S1_STEP(HmA, afrB)
+		afrA = frags[(tb + 1u) * 64u]; HmA = hmq[(tb + 1u) * 2u];
+		SP_S1_STEP(HmB, afrA)
 	}
-	word[0] = cylm_bits(g0, Hm, Dt[0], word[0]);
-	word[1] = cylm_bits(g1, Hm, Dt[1], word[1]);
+	if (tb < nblk) {
+		afrB = frags[tb * 64u]; HmB = hmq[tb * 2u];
+		SP_S1_STEP(HmA, afrB)
+		HmA = HmB;
+	}
+#undef SP_S1_STEP
+	word[0] = cylm_bits(g0, HmA, Dt[0], word[0]);
+	word[1] = cylm_bits(g1, HmA, Dt[1], word[1]);
 }
 
 constexpr uint32_t kMCap = 384u;             // list entries per wave and pass (16 bits each: group << 8 | ray << 2); what does not fit waits for the next pass
