@@ -30,6 +30,9 @@
 #undef SP_CYLM_GROUP
 
 namespace sp {
-constexpr uint32_t kMBigSceneTris = 32768u;       // from here on the 512-thread shape (measured crossover between 10^4 and 10^5 triangles)
+// from here on the 512-thread shape.  With octet bits it overtakes the 256-thread shape between 8192 and 12288 triangles of the closed room (tools/shape_crossover.py:
+// 0.98 / 1.02 / 1.03 / 1.07 / 1.08 / 1.12 at 8192 / 12288 / 16384 / 24576 / 32768 / 65536); scenes whose triangles are large for their number lose with it (stage 2
+// heavy: -25 % on the large-triangle scene at 10^4), hence not the very crossover.
+constexpr uint32_t kMBigSceneTris = 16384u;
 constexpr uint32_t kMIdxBits = cylm256::kMIdxBits;
 }

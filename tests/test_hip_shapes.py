@@ -1,5 +1,5 @@
 """The default scan exists in two workgroup shapes (spath_amd/csrc/sp_cylm_both.h): 256 threads with 256-triangle tiles for scenes
-below 32768 triangles, 512 threads with 512-triangle tiles above.  The library picks by scene size, so the small test scenes of the
+below 16384 triangles, 512 threads with 512-triangle tiles above.  The library picks by scene size, so the small test scenes of the
 other files only ever meet the first shape and the 1e5 / 1e6-triangle tests only the second.  Here SPATH_HIP_CYLM_SHAPE forces
 each shape onto the same small scenes: closest hits against the oracle (adversarial rays, idx_source), renders against the oracle
 (RGBA8, accumulators, scan counts: L-infinity = 0), triangle counts around the tile boundaries of both shapes, and the per-pair
@@ -75,10 +75,10 @@ def test_forced_shape_stage1_audit(shaped, O):
 
 
 def test_shape_follows_scene_size(hip):
-    """Without the override: 256-triangle tiles below 32768 triangles, 512 from there on."""
+    """Without the override: 256-triangle tiles below 16384 triangles, 512 from there on."""
     assert "SPATH_HIP_CYLM_SHAPE" not in os.environ
     rays = view.Camera(64, 1).get_viewport()
-    for n, want in ((20000, 256), (32767, 256), (32768, 512), (50000, 512)):
+    for n, want in ((10000, 256), (16383, 256), (16384, 512), (50000, 512)):
         t, m = scene.closed_room(n)
         hip.set_scene(t, m)
         assert _tiles(hip, rays)[1] == want, n
